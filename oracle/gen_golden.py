@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- regenerates tests/golden/ from the REAL reference CPU Go-ICP.
+
+Runs only in the build container (needs /root/reference).  It
+  1. builds oracle/_ref/ref_harness (oracle/Makefile: the reference's src/goicp/*.cpp compiled where
+     they lie + oracle/ref_harness.cpp),
+  2. runs the harness to produce the JSON fixtures (DT lookups, rotation radii, InnerBnB results,
+     ICP3D::Run results, 3x3 SVD rotations, exact NN, three end-to-end registrations),
+  3. converts the reference's own input clouds (data/bunny/*.txt -- data files, not source) into
+     little-endian float32 blobs so that the GPU box, which has no /root/reference, can replay them.
+
+usage: python oracle/gen_golden.py [--skip-full]     (full bunny e2e takes ~10 min of CPU)
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("GOICP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+BUNNY = os.path.join(REF, "data", "bunny")
+
+
+def txt_to_f32(harness, src, dst):
+    # parsed by the harness with "%f" (single rounding, as the reference's loader), not by numpy
+    n = int(subprocess.check_output([harness, "cloud", dst, src]).split()[0])
+    assert np.fromfile(dst, dtype="<f4").size == 3 * n
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference checkout not present: fixtures can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["make", "-C", HERE, "ref"])
+    h = os.path.join(HERE, "_ref", "ref_harness")
+    mb, db = os.path.join(BUNNY, "model_bunny.txt"), os.path.join(BUNNY, "data_bunny.txt")
+    mr, dr = os.path.join(BUNNY, "model_rand.txt"), os.path.join(BUNNY, "data_rand.txt")
+    for name, src in (("model_bunny", mb), ("data_bunny", db), ("model_rand", mr), ("data_rand", dr)):
+        n = txt_to_f32(h, src, os.path.join(OUT, name + ".f32"))
+        print(name, n, "points")
+    procs = [
+        subprocess.Popen([h, "units", OUT, mb, db, "10"], stdout=subprocess.DEVNULL),
+        subprocess.Popen([h, "e2e", OUT, "rand100", mr, dr, "1e-3", "1"], stdout=subprocess.DEVNULL),
+        subprocess.Popen([h, "e2e", OUT, "bunny10", mb, db, "1e-3", "10"], stdout=subprocess.DEVNULL),
+    ]
+    if not args.skip_full:
+        procs.append(subprocess.Popen([h, "e2e", OUT, "bunny_full", mb, db, "1e-3", "1"], stdout=subprocess.DEVNULL))
+    rc = [p.wait() for p in procs]
+    if any(rc):
+        sys.exit("harness failed: %r" % rc)
+    print("fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

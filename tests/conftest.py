@@ -1,0 +1,79 @@
+"""pytest plumbing: markers, paths, shared fixtures.
+
+`-m "not gpu"` tests run in the build container (no GPU): oracle vs golden vectors, host logic, C-ABI
+symbol table.  `-m gpu` tests are the parity tests proper and call the HIP path through the C-ABI.
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+def load_pkg():
+    """Import cuda-go-icp_amd/ (the hyphen keeps it from being a normal import name)."""
+    name = "cuda_go_icp_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "cuda-go-icp_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cloud(name, stride=1):
+    a = np.fromfile(os.path.join(GOLDEN, name + ".f32"), dtype="<f4").reshape(-1, 3)
+    return np.ascontiguousarray(a[::stride])
+
+
+def rot_angle(Ra, Rb):
+    """Geodesic angle between two rotations, from the chord ||Ra-Rb||_F = 2*sqrt(2)*sin(theta/2)
+    (well conditioned near 0, unlike arccos of the trace)."""
+    d = np.linalg.norm(np.asarray(Ra, dtype=np.float64).reshape(3, 3) - np.asarray(Rb, dtype=np.float64).reshape(3, 3))
+    return 2 * np.arcsin(min(1.0, d / (2 * np.sqrt(2))))
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def bunny_model():
+    return cloud("model_bunny")
+
+
+@pytest.fixture(scope="session")
+def bunny_data10():
+    return cloud("data_bunny", 10)
+
+
+@pytest.fixture(scope="session")
+def bunny_data():
+    return cloud("data_bunny")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def oracle_dt_bunny(oracle_mod, bunny_model):
+    return oracle_mod.DistanceTransform(bunny_model, 300, 2.0)

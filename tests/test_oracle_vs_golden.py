@@ -1,0 +1,160 @@
+"""Pins the CPU oracle (oracle/goicp_oracle.c) to the REAL reference.
+
+Every expected value below was produced by the reference's own CPU Go-ICP code
+(src/goicp/*, compiled unmodified in the build container by oracle/Makefile and driven by
+oracle/ref_harness.cpp; regenerate with `python oracle/gen_golden.py`).
+Tolerances follow SURVEY.md 8(c).
+"""
+import numpy as np
+import pytest
+
+from conftest import cloud, golden, rot_angle
+
+
+def test_dt_geometry_exact(oracle_dt_bunny):
+    g = golden("dt_lookup")
+    assert oracle_dt_bunny.V == g["SIZE"] == 300
+    assert oracle_dt_bunny.scale == g["scale"]                      # jly_3ddt.cpp:923, double, bit-exact
+    assert oracle_dt_bunny.origin == (g["xmin"], g["ymin"], g["zmin"])
+
+
+def test_dt_seed_count(oracle_dt_bunny, bunny_model):
+    _, n = oracle_dt_bunny.seed(bunny_model)
+    assert n == 32561
+
+
+def test_dt_lookup_vs_reference(oracle_dt_bunny):
+    """DT3D::Distance (jly_3ddt.cpp:981-1026) incl. out-of-grid extension and int() truncation.
+    Values: exact EDT vs the reference's propagated EDT -> <= 0.35 voxel, never below it."""
+    g = golden("dt_lookup")
+    q = np.array(g["query"]).reshape(-1, 3)
+    ref = np.array(g["distance"], dtype=np.float32)
+    mine = oracle_dt_bunny.distance(q)
+    vox = 1.0 / g["scale"]
+    assert np.all(mine <= ref + 1e-6)
+    assert np.max(ref - mine) <= 0.35 * vox
+    assert np.mean(mine == ref) > 0.999                             # index math exact
+
+
+def test_dt_voxels_vs_reference(oracle_dt_bunny):
+    g = golden("dt_lookup")
+    v = np.array(g["voxel"]).reshape(-1, 3)
+    ref = np.array(g["voxel_distance"], dtype=np.float32)
+    mine = oracle_dt_bunny.grid()[v[:, 2], v[:, 1], v[:, 0]]
+    vox = 1.0 / g["scale"]
+    assert np.all(mine <= ref + 1e-7)
+    assert np.max(ref - mine) <= 0.35 * vox
+
+
+def test_dt_is_exact_edt_of_seed_grid(oracle_mod):
+    """The oracle's DT build against scipy's exact EDT on a smaller grid."""
+    from scipy import ndimage
+    model = cloud("model_bunny")
+    dt = oracle_mod.DistanceTransform(model, 96, 2.0)
+    seed, _ = dt.seed(model)
+    ref = ndimage.distance_transform_edt(seed == 0)
+    expect = (np.sqrt((ref ** 2).round()).astype(np.float32).astype(np.float64) / dt.scale).astype(np.float32)
+    assert np.array_equal(dt.grid(), expect)
+
+
+def test_rot_radii_bit_exact(oracle_mod, bunny_data10):
+    g = golden("rot_radii")
+    _, rho = oracle_mod.rot_radii(bunny_data10)
+    ref = np.array(g["maxRotDis"], dtype=np.float32)
+    assert np.array_equal(rho[:, :64], ref)                          # jly_goicp.cpp:139-160
+
+
+def test_inner_bnb_single_expansions(oracle_mod, oracle_dt_bunny, bunny_data10):
+    """One expansion of GoICP::InnerBnB (jly_goicp.cpp:262-336): min ub over the 8 children and the
+    arg-min child.  rel 1e-4 (float summation order: the reference permutes minDis first)."""
+    g = golden("inner_bnb")
+    _, rho = oracle_mod.rot_radii(bunny_data10)
+    n = 0
+    for case in g["cases"]:
+        prot = oracle_mod.rotate(np.array(case["R"], dtype=np.float32).reshape(3, 3), bunny_data10)
+        for s in case["single"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, cubes = oracle_mod.inner_bnb(oracle_dt_bunny, prot, r, 1e10, 1e9, root=s["parent"])
+            assert pops == s["pops"] and cubes == 8
+            assert abs(v - s["min_ub"]) <= 1e-4 * max(s["min_ub"], 1e-3)
+            assert np.array_equal(best, np.array(s["best"], dtype=np.float32))
+            n += 1
+    assert n == 384
+
+
+def test_inner_bnb_full_searches(oracle_mod, oracle_dt_bunny, bunny_data10):
+    """Whole InnerBnB calls: value rel 1e-3, best node identical, node pops within 1 %."""
+    g = golden("inner_bnb")
+    _, rho = oracle_mod.rot_radii(bunny_data10)
+    for case in g["cases"]:
+        prot = oracle_mod.rotate(np.array(case["R"], dtype=np.float32).reshape(3, 3), bunny_data10)
+        for s in case["full"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, _ = oracle_mod.inner_bnb(oracle_dt_bunny, prot, r, s["incumbent"], g["sse_threshold"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+            if s["value"] < s["incumbent"] and s["level"] < 0:
+                assert np.array_equal(best, np.array(s["best"], dtype=np.float32))
+
+
+def test_nn_exact(oracle_mod, bunny_model):
+    g = golden("nn")
+    q = np.array(g["query"], dtype=np.float32).reshape(-1, 3)
+    kd = oracle_mod.KdTree(bunny_model)
+    idx, d2 = kd.nn(q)
+    assert np.array_equal(d2, np.array(g["dist_sq"], dtype=np.float32))   # nanoflann_goicp.hpp:1137-1184
+    assert np.mean(idx == np.array(g["index"])) > 0.999                   # ties only
+    bi, bd = oracle_mod.nn_brute(bunny_model, q[:256])
+    assert np.array_equal(bd, d2[:256]) and np.array_equal(bi, idx[:256])
+
+
+def test_kabsch_rotation(oracle_mod):
+    g = golden("svd3x3")
+    for c in g["cases"]:
+        R = oracle_mod.kabsch_rotation(c["H"])
+        assert np.abs(R - np.array(c["R"]).reshape(3, 3)).max() <= 1e-5   # jly_icp3d.hpp:268-285
+
+
+def test_icp_run(oracle_mod, bunny_model, bunny_data10):
+    """ICP3D<float>::Run (jly_icp3d.hpp:181-295) with forced iteration counts. 1e-4 abs on R, t
+    for <= 10 iterations; the converged runs are compared at 1e-3."""
+    g = golden("icp_iter")
+    kd = oracle_mod.KdTree(bunny_model)
+    for c in g["cases"]:
+        err, R, t, it = kd.icp_run(bunny_data10, c["R0"], c["t0"], c["max_iter"], c["err_diff"])
+        tol = 1e-4 if c["max_iter"] <= 10 else 1e-3
+        assert np.abs(R.ravel() - np.array(c["R"])).max() <= tol
+        assert np.abs(t - np.array(c["t"])).max() <= tol
+        assert abs(err - c["err"]) <= 1e-3 * c["err"]
+        if c["max_iter"] <= 10:
+            assert it == c["max_iter"]
+
+
+def test_icp_dt_score(oracle_mod, oracle_dt_bunny, bunny_data10):
+    g = golden("icp_dt_score")
+    sse = oracle_mod.dt_sse(oracle_dt_bunny, bunny_data10, np.array(g["R"]).reshape(3, 3), g["t"])
+    assert abs(sse - g["dt_sse"]) <= 1e-4 * g["dt_sse"]                  # jly_goicp.cpp:93-132
+
+
+def _check_e2e(oracle_mod, tag, model, data):
+    g = golden("e2e_" + tag)
+    dt = oracle_mod.DistanceTransform(model, 300, 2.0)
+    r = oracle_mod.register(dt, model, data, g["mse_threshold"])
+    Rg = np.array(g["R"]).reshape(3, 3)
+    assert rot_angle(r["R"], Rg) <= 2e-3
+    assert np.linalg.norm(r["t"] - np.array(g["t"])) <= 2e-3
+    assert abs(r["sse"] - g["sse"]) <= 0.02 * g["sse"]
+    assert r["sse"] < g["sse_threshold"] or g["sse"] >= g["sse_threshold"]
+    return r, g
+
+
+def test_e2e_rand100(oracle_mod):
+    r, g = _check_e2e(oracle_mod, "rand100", cloud("model_rand"), cloud("data_rand"))
+    assert r["rot_pops"] == g["rNodeCount"] and r["trans_pops"] == g["tNodeCount"]
+
+
+@pytest.mark.slow
+def test_e2e_bunny10(oracle_mod, bunny_model, bunny_data10):
+    r, g = _check_e2e(oracle_mod, "bunny10", bunny_model, bunny_data10)
+    assert r["rot_pops"] == g["rNodeCount"]
+    assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- BnB cube bounds/sec (+ inner-ICP iterations/sec) of the MI355X Go-ICP engine.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run,
+one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], "bunny_goicp.toml Go-ICP on 1xMI355X, DT grid 300^3,
+subsample=1.0"): the Stanford-bunny clouds the reference's config names (M = 35 947 target,
+N = 30 379 source; committed data fixtures, tests/golden/*.f32), distance transform 300^3.
+  step   = one pass of the hot path over one batch: ONE launch of the cube-bound evaluator over
+           B = 65 536 translation sub-cubes (8 192 BnB expansions x 8 children, widths 1/2 .. 1/64,
+           spread over 8 rotations, every second expansion a lower-bound pass with rotation radii),
+           followed -- as in the sharded search -- by the min-reduction of the best upper bound
+           (device-side min; all-reduced over RCCL when N > 1).  Inputs are resident in HBM.
+  value  = cube bounds evaluated by all ranks / wall time of the K timed steps (max over ranks).
+Also reported: ICP iterations/s (NN + sums + SVD update, host round trip included), an end-to-end
+registration of the same clouds (exact cube-bound count / wall time), the roofline of the dominant
+kernel (HIP events on the launch stream) and the CPU oracle timed on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def make_batch(pkg, reg, n_expansions, n_rot, seed):
+    """Cube records exactly as the engine's BnB driver generates them (engine.cpp run_inner)."""
+    from cuda_go_icp_amd import binding as B
+    rng = np.random.default_rng(seed)
+    rots = np.stack([pkg.fgoicp.rodrigues(rng.uniform(-2.0, 2.0, 3)) for _ in range(n_rot)]).astype(np.float32)
+    recs = np.zeros(n_expansions * 8, dtype=[("tx", "<f4"), ("ty", "<f4"), ("tz", "<f4"), ("delta", "<f4"),
+                                              ("coeff", "<f4"), ("rot", "<i4")])
+    lev = rng.integers(0, 6, n_expansions)                 # parent widths 1 .. 1/32 -> child widths 1/2 .. 1/64
+    pw = (1.0 / (1 << lev)).astype(np.float32)
+    corner = (rng.uniform(-0.5, 0.5, (n_expansions, 3)) * (1 - pw[:, None]) - pw[:, None] / 2).astype(np.float32)
+    w = pw / np.float32(2)
+    j = np.arange(8)
+    off = np.stack([(j & 1), (j >> 1) & 1, (j >> 2) & 1], 1).astype(np.float32)         # (8,3)
+    cx = corner[:, None, :] + off[None, :, :] * w[:, None, None] + (w / np.float32(2))[:, None, None]
+    recs["tx"], recs["ty"], recs["tz"] = cx[..., 0].ravel(), cx[..., 1].ravel(), cx[..., 2].ravel()
+    delta = np.array([reg._lib.goicp_trans_delta(float(x)) for x in np.unique(w)], np.float32)
+    dmap = dict(zip(np.unique(w).tolist(), delta.tolist()))
+    recs["delta"] = np.repeat(np.array([dmap[float(x)] for x in w], np.float32), 8)
+    lb_pass = (np.arange(n_expansions) % 2) == 1
+    rot_level = rng.integers(3, 9, n_expansions)
+    coeff = np.array([float(reg.rot_coeff(int(l))) for l in range(20)], np.float32)
+    recs["coeff"] = np.repeat(np.where(lb_pass, coeff[rot_level], np.float32(0)), 8)
+    recs["rot"] = np.repeat((np.arange(n_expansions) * n_rot) // n_expansions, 8)       # grouped by rotation
+    n_lb = int(lb_pass.sum()) * 8
+    return rots, recs, n_lb
+
+
+def cpu_baseline(reg, model, data, seconds=6.0):
+    """The CPU oracle (a port of the reference's InnerBnB body) on the same DT, 1 thread and all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    V, scale, origin = reg.dt_info()
+    dt = O.DistanceTransform.wrap(V, scale, origin[0], origin[1], origin[2], reg.dt_download())
+    R = O.rodrigues([0.3, -0.2, 0.9])
+    prot = O.rotate(R, data)
+    _, rho = O.rot_radii(data)
+    rng = np.random.default_rng(2)
+    out = {}
+    for name, omp in (("1thread", False), ("allcores", True)):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(16):
+                c = rng.uniform(-0.4, 0.4, 3)
+                O.cube_bound(dt, prot, rho[5] if n % 2 else None, c, 0.0625, omp=omp)
+                n += 1
+        out[name] = n / (time.perf_counter() - t0)
+    kd = O.KdTree(model)
+    t0 = time.perf_counter()
+    _, _, _, it = kd.icp_run(data, np.eye(3), np.zeros(3), 8, -1e30)
+    out["icp_iters_per_s_1thread"] = it / (time.perf_counter() - t0)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--expansions", type=int, default=8192, help="BnB expansions (x8 cubes) per step per GPU")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--dt-layout", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from __graft_entry__ import _pkg
+    pkg = _pkg()
+    pkg.load_library()
+    from cuda_go_icp_amd import binding as B
+    g = os.path.join(ROOT, "tests", "golden")
+    model = np.fromfile(os.path.join(g, "model_bunny.f32"), dtype="<f4").reshape(-1, 3)
+    data = np.fromfile(os.path.join(g, "data_bunny.f32"), dtype="<f4").reshape(-1, 3)
+    N, M, V = len(data), len(model), 300
+
+    reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank)
+    lib, h = reg._lib, reg.handle
+    rots, recs, n_lb = make_batch(pkg, reg, args.expansions, 8, seed=1234 + rank)
+    Bc = len(recs)
+    d_rots = torch.from_numpy(rots.reshape(-1)).to(dev)
+    d_cubes = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+    d_ub = torch.empty(Bc, dtype=torch.float32, device=dev)
+    d_lb = torch.empty(Bc, dtype=torch.float32, device=dev)
+    best = torch.empty(1, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))
+        torch.amin(d_ub, dim=0, keepdim=True, out=best)          # best upper bound of the batch
+        if world > 1:
+            dist.all_reduce(best, op=dist.ReduceOp.MIN)          # RCCL: prune globally
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    value = world * Bc * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events on the launch stream, live ----
+        ms = C.c_float()
+        B.check(lib.goicp_time_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), 10, C.byref(ms)))
+        alg_bytes = (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N      # 16N ub pass, 20N lb pass
+        achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
+        # ---- ICP iterations/s ----
+        Ri, ti = np.eye(3, dtype=np.float32).reshape(9).copy(), np.zeros(3, np.float32)
+        err, it = C.c_float(), C.c_int32()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 5, -1e30, C.byref(err), C.byref(it)))
+        t1 = time.perf_counter()
+        B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 200, -1e30, C.byref(err), C.byref(it)))
+        icp_rate = it.value / (time.perf_counter() - t1)
+        B.check(lib.goicp_time_icp_pass(h, fp(Ri), fp(ti), 50, C.byref(ms)))
+        D = int(np.ceil(np.log2(M / 8.0)))
+        icp_bytes = N * (16.0 + D * 8.0 + 8 * 16.0)               # query + root-to-leaf nodes (8 B) + one leaf of 8 float4 points
+        icp = {"icp_iters_per_s": round(icp_rate, 1), "icp_pass_kernel_ms": round(ms.value, 4),
+               "icp_pass_algorithmic_GBs": round(icp_bytes / (ms.value * 1e-3) / 1e9, 1), "icp_bytes_per_iter": icp_bytes}
+        # ---- end-to-end registration of the same clouds ----
+        e2e = None
+        if not args.no_e2e:
+            eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank)
+            t1 = time.perf_counter()
+            eng.run()
+            wall = time.perf_counter() - t1
+            r = eng.registration.poll()
+            e2e = {"register_s": round(wall, 4), "sse": float(r.best_sse), "cube_bounds": int(r.counters.cubes),
+                   "cube_bounds_per_s": round(r.counters.cubes / wall, 1), "rot_pops": int(r.counters.rot_pops),
+                   "trans_pops": int(r.counters.trans_pops), "icp_iters": int(r.counters.icp_iters),
+                   "dt_build_ms": round(r.dt_build_ms, 2), "reference_cpu_register_s": 502.7, "reference_sse": 4.57226}
+        cpu = None
+        if not args.no_cpu:
+            c = cpu_baseline(reg, model, data)
+            cpu = {"value": round(c["1thread"], 1), "unit": "cube-bounds/s", "cores": 1, "kind": "port",
+                   "sample": "oracle cube_bound (restated InnerBnB body) on the same DT/cloud, ~6 s, alternating ub/lb passes",
+                   "allcores_value": round(c["allcores"], 1), "allcores": os.cpu_count(),
+                   "icp_iters_per_s_1thread": round(c["icp_iters_per_s_1thread"], 2)}
+        out = {"metric": "bnb_cube_bounds_per_s", "value": round(value, 1), "unit": "cube-bounds/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "Stanford-bunny clouds named by the reference's bunny_goicp.toml (committed fixture) + synthetic cube batch",
+               "config": {"workload": "bunny_goicp.toml (BASELINE configs[1]): N=%d source, M=%d target, DT %d^3, subsample 1.0" % (N, M, V),
+                          "cubes_per_step_per_gpu": Bc, "lb_pass_fraction": n_lb / Bc, "rotations_per_step": 8,
+                          "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) best ub" if world > 1 else "local min"},
+               "roofline": roofline, "cpu_baseline": cpu, "icp": icp, "e2e": e2e}
+        print(json.dumps(out), flush=True)
+    reg.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""ctypes binding of libgoicp_mi355.so (include/goicp_mi355.h)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK = 0
+STATUS = {-1: "GOICP_ERR_INVALID", -2: "GOICP_ERR_IO", -3: "GOICP_ERR_CONFIG", -4: "GOICP_ERR_NO_DEVICE",
+          -5: "GOICP_ERR_DEVICE", -6: "GOICP_ERR_INTERNAL"}
+PATH_MAX = 1024
+
+
+class GoicpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, str(code)), msg))
+        self.code = code
+
+
+class CConfig(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("trim", C.c_int32), ("subsample", C.c_float), ("mse_threshold", C.c_float),
+                ("resize", C.c_float), ("target", C.c_char * PATH_MAX), ("source", C.c_char * PATH_MAX),
+                ("output", C.c_char * PATH_MAX), ("visualization", C.c_char * PATH_MAX),
+                ("viz_theta", C.c_float), ("viz_phi", C.c_float), ("viz_spin_after_finish", C.c_int32),
+                ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3), ("rot_search_depth", C.c_int32),
+                ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("trans_search_depth", C.c_int32),
+                ("description", C.c_char * PATH_MAX)]
+
+
+class CParams(C.Structure):
+    _fields_ = [("dt_size", C.c_int32), ("dt_expand", C.c_double), ("mse_threshold", C.c_float),
+                ("dt_layout", C.c_int32), ("device", C.c_int32), ("trans_batch", C.c_int32),
+                ("wide_children", C.c_int32), ("icp_max_iter", C.c_int32), ("verbose", C.c_int32),
+                ("morton_sort", C.c_int32)]
+
+
+class CCube(C.Structure):
+    _fields_ = [("tx", C.c_float), ("ty", C.c_float), ("tz", C.c_float), ("delta", C.c_float),
+                ("coeff", C.c_float), ("rot", C.c_int32)]
+
+
+class CCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("rot_pops", "trans_pops", "cubes", "inner_calls", "icp_runs", "icp_iters",
+                                         "bounds_launches")]
+
+
+class CResult(C.Structure):
+    _fields_ = [("optR", C.c_float * 9), ("optT", C.c_float * 3), ("curR", C.c_float * 9), ("curT", C.c_float * 3),
+                ("best_sse", C.c_float), ("finished", C.c_int32), ("counters", CCounters),
+                ("dt_build_ms", C.c_double), ("register_ms", C.c_double)]
+
+
+class CStepStatus(C.Structure):
+    _fields_ = [("finished", C.c_int32), ("early_exit", C.c_int32), ("best_sse", C.c_float),
+                ("frontier_lb", C.c_float), ("rot_pops", C.c_int64)]
+
+
+# every symbol include/goicp_mi355.h declares: name -> (restype, argtypes)
+_fp, _vp = C.POINTER(C.c_float), C.c_void_p
+SYMBOLS = {
+    "goicp_last_error": (C.c_char_p, []),
+    "goicp_abi_version": (C.c_int, []),
+    "goicp_config_load": (C.c_int, [C.c_char_p, C.POINTER(CConfig)]),
+    "goicp_cloud_load": (C.c_int, [C.c_char_p, C.c_float, C.c_float, C.c_uint64, C.POINTER(_fp), C.POINTER(C.c_size_t)]),
+    "goicp_cloud_free": (None, [_fp]),
+    "goicp_params_default": (None, [C.POINTER(CParams)]),
+    "goicp_create": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.POINTER(_vp)]),
+    "goicp_destroy": (C.c_int, [_vp]),
+    "goicp_dt_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "goicp_dt_download": (C.c_int, [_vp, _fp]),
+    "goicp_eval_bounds": (C.c_int, [_vp, _fp, _fp, C.c_size_t, C.c_int32, _fp, _fp]),
+    "goicp_eval_bounds_batch": (C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(CCube), C.c_size_t, _fp, _fp]),
+    "goicp_eval_bounds_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "goicp_time_bounds_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, _fp]),
+    "goicp_rot_coeff": (C.c_float, [_vp, C.c_int32]),
+    "goicp_trans_delta": (C.c_float, [C.c_float]),
+    "goicp_rodrigues": (None, [_fp, _fp]),
+    "goicp_eval_sse": (C.c_int, [_vp, _fp, _fp, _fp]),
+    "goicp_inner_bnb": (C.c_int, [_vp, _fp, C.c_int32, C.c_float, _fp, _fp, C.POINTER(CCounters)]),
+    "goicp_icp_run": (C.c_int, [_vp, _fp, _fp, C.c_int32, C.c_float, _fp, C.POINTER(C.c_int32)]),
+    "goicp_time_icp_pass": (C.c_int, [_vp, _fp, _fp, C.c_int32, _fp]),
+    "goicp_nn_query": (C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_int32), _fp]),
+    "goicp_icp_step": (C.c_int, [_vp]),
+    "goicp_register": (C.c_int, [_vp]),
+    "goicp_cancel": (C.c_int, [_vp]),
+    "goicp_poll": (C.c_int, [_vp, C.POINTER(CResult)]),
+    "goicp_result_write_toml": (C.c_int, [_vp, C.c_char_p]),
+    "goicp_transform_source": (C.c_int, [_vp, _fp, _fp, _fp]),
+    "goicp_set_shard": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "goicp_register_begin": (C.c_int, [_vp]),
+    "goicp_register_step": (C.c_int, [_vp, C.c_int32, C.POINTER(CStepStatus)]),
+    "goicp_offer_best": (C.c_int, [_vp, C.c_float, _fp, _fp]),
+    "goicp_register_end": (C.c_int, [_vp]),
+}
+
+
+def library_path():
+    return os.path.join(HERE, "libgoicp_mi355.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(HERE, "csrc"), "all"]
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc"), "clean"])
+    subprocess.check_call(args)
+    return library_path()
+
+
+def load_library():
+    """Load the HIP library.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise GoicpError(-6, "libgoicp_mi355.so is not built (run __graft_entry__.build() or make -C cuda-go-icp_amd/csrc)")
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI and the header disagree
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(code):
+    if code != OK:
+        raise GoicpError(code, load_library().goicp_last_error().decode("utf-8", "replace"))

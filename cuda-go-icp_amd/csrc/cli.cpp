@@ -1,0 +1,74 @@
+// goicp_cli: headless replacement for the reference's viewer main (src/main.cpp:14-187).  Takes the
+// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--verbose] [--seed S]
+//   modes 0/1/2 (plain ICP, src/main.cpp:99-110): N ICP iterations (the reference iterates forever; default 50)
+//   modes 3/4   (Go-ICP,   src/main.cpp:111-141): full registration
+// Prints the result the way the reference logs it and writes io.output (output.toml) when set.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/goicp_mi355.hpp"
+
+using namespace goicp_mi355;
+struct P3 { float x, y, z; };
+
+static std::string resolve(const std::string& p, const std::string& toml)
+{
+	if (p.empty() || p[0] == '/') return p;
+	FILE* f = std::fopen(p.c_str(), "rb");
+	if (f) { std::fclose(f); return p; }
+	size_t s = toml.find_last_of("/\\");
+	return s == std::string::npos ? p : toml.substr(0, s + 1) + p;
+}
+
+int main(int argc, char** argv)
+{
+	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--verbose] [--seed S]\n"); return 2; }
+	int iters = 50, verbose = 0;
+	unsigned long long seed = 0;
+	for (int i = 2; i < argc; i++) {
+		if (!std::strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
+		else if (!std::strcmp(argv[i], "--verbose")) verbose = 1;
+	}
+	try {
+		Config config(argv[1]);
+		std::vector<P3> source, target;
+		load_cloud(resolve(config.io.source, argv[1]), config.subsample, config.resize, source, seed);
+		load_cloud(resolve(config.io.target, argv[1]), config.subsample, config.resize, target, seed);
+		std::printf("mode %d: source %zu points, target %zu points, mse_threshold %g\n", config.mode, source.size(),
+		            target.size(), config.mse_threshold);
+		goicp_params p;
+		goicp_params_default(&p);
+		p.verbose = verbose;
+		std::mutex mtx;
+		icp::FastGoICP engine(target, source, config.mse_threshold, mtx, &p);
+		goicp_handle h = engine.registration.handle();
+		goicp_result r;
+		if (config.mode <= 2) {
+			for (int i = 0; i < iters; i++) check(goicp_icp_step(h));
+			check(goicp_poll(h, &r));
+			std::printf("ICP after %d iterations: SSE %.7g\n", iters, r.best_sse);
+		} else {
+			engine.run();
+			check(goicp_poll(h, &r));
+			std::printf("Searching over! Best Error: %.7g  (MSE %.7g)\n", r.best_sse, r.best_sse / (float)source.size());
+			std::printf("Total Translation Nodes Searched: %lld\nTotal Rotation Nodes Searched: %lld\n",
+			            (long long)r.counters.trans_pops, (long long)r.counters.rot_pops);
+			std::printf("cube bounds %lld in %.1f ms (DT build %.1f ms)\n", (long long)r.counters.cubes, r.register_ms, r.dt_build_ms);
+		}
+		const float* R = config.mode <= 2 ? r.curR : r.optR;
+		const float* t = config.mode <= 2 ? r.curT : r.optT;
+		std::printf("Optimal Rotation Matrix:\n");
+		for (int i = 0; i < 3; i++) std::printf("%12.7f %12.7f %12.7f\n", R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+		std::printf("Optimal Translation Vector:\n%12.7f\n%12.7f\n%12.7f\n", t[0], t[1], t[2]);
+		if (!config.io.output.empty()) engine.write_output(config.io.output);
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return 1;
+	}
+	return 0;
+}

@@ -1,0 +1,803 @@
+// Engine: resident data set-up, batched branch-and-bound driver, ICP loop.
+//
+// Search semantics = reference CPU Go-ICP (src/goicp/jly_goicp.cpp):
+//   outer best-first BnB over the angle-axis cube [-pi,pi]^3 (OuterBnB, :342-567), nested
+//   best-first BnB over the translation cube [-0.5,0.5]^3 (InnerBnB, :227-340), ICP refinement
+//   whenever the upper bound improves (:495-530), stop when best - lb <= SSEThresh.
+// What is MI355X-first here: the reference evaluates ONE cube per step; this driver keeps the same
+// bounds and the same queues but expands `trans_batch` translation nodes of up to 8 concurrent
+// inner searches per kernel launch (thousands of cube x point evaluations per launch instead of
+// one pass over N points).  Any expansion order of a best-first BnB yields valid bounds; with
+// trans_batch = 1 and wide_children = 0 the visit order is exactly the reference's.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace goicp {
+
+namespace {
+
+// constants spelled as the reference does (jly_goicp.h:35-36)
+constexpr double kPI = 3.1415926536;
+constexpr double kSQRT3 = 1.732050808;
+constexpr int kMaxRotLevel = 20;
+
+void hip_check(hipError_t e, const char* what)
+{
+	if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint32_t part1by2(uint32_t x)
+{
+	x &= 0x3ff;
+	x = (x ^ (x << 16)) & 0xff0000ff;
+	x = (x ^ (x << 8)) & 0x0300f00f;
+	x = (x ^ (x << 4)) & 0x030c30c3;
+	x = (x ^ (x << 2)) & 0x09249249;
+	return x;
+}
+
+}  // namespace
+
+struct Engine::InnerSearch {
+	int rot_slot = 0;
+	float coeff = 0.f;            // 0 => upper-bound pass (maxRotDisL == NULL)
+	float best = 0.f;             // optErrorT
+	Node best_node{};
+	bool improved = false;
+	bool done = false;
+	std::priority_queue<Node> pq;
+	std::vector<Node> parents;    // popped this round
+	long long pops = 0, cubes = 0;
+};
+
+float Engine::rot_coeff(int level) const
+{
+	if (level < 0) return 0.f;
+	return rot_coeff_[level < kMaxRotLevel ? level : kMaxRotLevel - 1];
+}
+
+Engine::Engine(const Params& p, const float* target, size_t M, const float* source, size_t N)
+    : p_(p), M_(M), N_(N)
+{
+	if (!target || !source || M == 0 || N == 0) throw std::invalid_argument("goicp: empty target or source cloud");
+	if (M > (size_t)INT32_MAX / 8 || N > (size_t)INT32_MAX / 8) throw std::invalid_argument("goicp: cloud too large");
+	if (p_.dt_size < 8 || p_.dt_size > 1024) throw std::invalid_argument("goicp: dt_size must be in [8,1024]");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		throw std::runtime_error("goicp: no HIP device available (this engine has no CPU fallback)");
+	if (p_.device >= 0) HIPCHK(hipSetDevice(p_.device));
+	HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+	HIPCHK(hipEventCreate(&ev0_));
+	HIPCHK(hipEventCreate(&ev1_));
+
+	sse_thresh_ = p_.mse_threshold * (float)N_;      // jly_goicp.cpp:208 (inlierNum = Nd)
+	icp_err_diff_ = p_.mse_threshold / 10000;        // jly_goicp.cpp:186
+
+	// rotation uncertainty coefficients per level (jly_goicp.cpp:153-159)
+	for (int l = 0; l < kMaxRotLevel; l++) {
+		float w0 = (float)(2 * kPI);
+		float sigma = (float)((double)w0 / std::pow(2.0, l) / 2.0);
+		float maxAngle = (float)(kSQRT3 * (double)sigma);
+		if ((double)maxAngle > kPI) maxAngle = (float)kPI;
+		rot_coeff_[l] = 2 * std::sin(maxAngle / 2);
+	}
+
+	// ---- source cloud: (x,y,z,|p|), Morton order ----
+	{
+		std::vector<int32_t> perm(N_);
+		for (size_t i = 0; i < N_; i++) perm[i] = (int32_t)i;
+		if (p_.morton_sort) {
+			float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+			for (size_t i = 0; i < N_; i++)
+				for (int k = 0; k < 3; k++) {
+					mn[k] = std::min(mn[k], source[3 * i + k]);
+					mx[k] = std::max(mx[k], source[3 * i + k]);
+				}
+			float ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-30f});
+			std::vector<uint32_t> code(N_);
+			for (size_t i = 0; i < N_; i++) {
+				uint32_t c = 0;
+				for (int k = 0; k < 3; k++) {
+					float f = (source[3 * i + k] - mn[k]) / ext;
+					uint32_t q = (uint32_t)std::min(1023.f, std::max(0.f, f * 1024.f));
+					c |= part1by2(q) << k;
+				}
+				code[i] = c;
+			}
+			std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
+		}
+		src_perm_ = perm;
+		h_src_sorted_.resize(4 * N_);
+		double cs[3] = {0, 0, 0};
+		for (size_t i = 0; i < N_; i++) {
+			const float* s = source + 3 * (size_t)perm[i];
+			float x = s[0], y = s[1], z = s[2];
+			h_src_sorted_[4 * i] = x; h_src_sorted_[4 * i + 1] = y; h_src_sorted_[4 * i + 2] = z;
+			h_src_sorted_[4 * i + 3] = std::sqrt(x * x + y * y + z * z);   // normData, jly_goicp.cpp:145
+			cs[0] += x; cs[1] += y; cs[2] += z;
+		}
+		for (int k = 0; k < 3; k++) src_centroid_[k] = (float)(cs[k] / (double)N_);
+		HIPCHK(hipMalloc(&d_src_, sizeof(float4) * N_));
+		HIPCHK(hipMemcpy(d_src_, h_src_sorted_.data(), sizeof(float4) * N_, hipMemcpyHostToDevice));
+	}
+
+	// ---- distance transform geometry (jly_3ddt.cpp:891-923), double ----
+	{
+		double xMin = target[0], xMax = target[0], yMin = target[1], yMax = target[1], zMin = target[2], zMax = target[2];
+		double cm[3] = {0, 0, 0};
+		for (size_t i = 0; i < M_; i++) {
+			double x = target[3 * i], y = target[3 * i + 1], z = target[3 * i + 2];
+			if (xMin > x) xMin = x;
+			if (xMax < x) xMax = x;
+			if (yMin > y) yMin = y;
+			if (yMax < y) yMax = y;
+			if (zMin > z) zMin = z;
+			if (zMax < z) zMax = z;
+			cm[0] += x; cm[1] += y; cm[2] += z;
+		}
+		for (int k = 0; k < 3; k++) model_centroid_[k] = (float)(cm[k] / (double)M_);
+		const double ex = p_.dt_expand;
+		double xc = (xMin + xMax) / 2, yc = (yMin + yMax) / 2, zc = (zMin + zMax) / 2;
+		xMin = xc - ex * (xMax - xc); xMax = xc + ex * (xMax - xc);
+		yMin = yc - ex * (yMax - yc); yMax = yc + ex * (yMax - yc);
+		zMin = zc - ex * (zMax - zc); zMax = zc + ex * (zMax - zc);
+		double side = xMax - xMin > yMax - yMin ? xMax - xMin : yMax - yMin;
+		side = side > zMax - zMin ? side : zMax - zMin;
+		if (!(side > 0)) throw std::invalid_argument("goicp: degenerate target cloud (zero extent)");
+		dt_.V = p_.dt_size;
+		dt_.VB = (p_.dt_size + 3) / 4;
+		dt_.layout = p_.dt_layout ? 1 : 0;
+		dt_.xmin = xc - side / 2; dt_.ymin = yc - side / 2; dt_.zmin = zc - side / 2;
+		dt_.scale = dt_.V / side;
+	}
+	// ---- DT build on the GPU ----
+	{
+		double t0 = now_ms();
+		const size_t V = dt_.V, nlin = V * V * V;
+		const size_t nout = dt_.layout ? (size_t)dt_.VB * dt_.VB * dt_.VB * 64 : nlin;
+		float* d_model = nullptr;
+		int32_t* d_work = nullptr;
+		HIPCHK(hipMalloc(&d_model, sizeof(float) * 3 * M_));
+		HIPCHK(hipMemcpyAsync(d_model, target, sizeof(float) * 3 * M_, hipMemcpyHostToDevice, stream_));
+		HIPCHK(hipMalloc(&d_work, sizeof(int32_t) * nlin));
+		if (dt_.layout) {
+			HIPCHK(hipMalloc(&d_dt_, sizeof(float) * nout));
+			HIPCHK(hipMemsetAsync(d_dt_, 0, sizeof(float) * nout, stream_));
+		} else {
+			d_dt_ = reinterpret_cast<float*>(d_work);
+		}
+		dt_.grid = d_dt_;
+		HIPCHK(launch_dt_build(d_model, (int)M_, dt_, d_work, d_dt_, stream_));
+		HIPCHK(hipStreamSynchronize(stream_));
+		HIPCHK(hipFree(d_model));
+		if (dt_.layout) HIPCHK(hipFree(d_work));
+		dt_build_ms_ = now_ms() - t0;
+	}
+	// ---- k-d tree over the target ----
+	{
+		KdHost kh;
+		build_kdtree(target, (int)M_, 8, &kh);
+		HIPCHK(hipMalloc(&d_kd_nodes_, sizeof(float2) * kh.nodes.size()));
+		HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
+		HIPCHK(hipMalloc(&d_kd_leaf_, sizeof(int32_t) * kh.leaf_start.size()));
+		HIPCHK(hipMemcpy(d_kd_nodes_, kh.nodes.data(), sizeof(float2) * kh.nodes.size(), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d_kd_leaf_, kh.leaf_start.data(), sizeof(int32_t) * kh.leaf_start.size(), hipMemcpyHostToDevice));
+		kd_.nodes = d_kd_nodes_; kd_.pts = d_kd_pts_; kd_.leaf_start = d_kd_leaf_; kd_.L = kh.L; kd_.M = (int)M_;
+	}
+	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)icp_blocks((int)N_) * kIcpAcc));
+	HIPCHK(hipMalloc(&d_icp_out_, sizeof(double) * kIcpAcc));
+	HIPCHK(hipHostMalloc(&h_icp_out_, sizeof(double) * kIcpAcc));
+	ensure_batch(4096, 64);
+
+	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	std::memcpy(optR_, I, sizeof(I)); std::memcpy(curR_, I, sizeof(I)); std::memcpy(stepR_, I, sizeof(I));
+	std::memset(optT_, 0, sizeof(optT_)); std::memset(curT_, 0, sizeof(curT_)); std::memset(stepT_, 0, sizeof(stepT_));
+	publish(false);
+}
+
+Engine::~Engine()
+{
+	hipStreamSynchronize(stream_);
+	hipFree(d_src_); hipFree(d_dt_);
+	hipFree(d_kd_nodes_); hipFree(d_kd_pts_); hipFree(d_kd_leaf_);
+	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
+	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
+	hipFree(d_icp_partials_); hipFree(d_icp_out_); hipHostFree(h_icp_out_);
+	hipEventDestroy(ev0_); hipEventDestroy(ev1_);
+	hipStreamDestroy(stream_);
+}
+
+void Engine::ensure_batch(size_t B, size_t K)
+{
+	if (B > cap_cubes_) {
+		size_t cap = std::max<size_t>(B, cap_cubes_ * 2);
+		hipStreamSynchronize(stream_);
+		hipFree(d_cubes_); hipFree(d_ub_); hipFree(d_lb_);
+		hipHostFree(h_cubes_); hipHostFree(h_ub_); hipHostFree(h_lb_);
+		HIPCHK(hipMalloc(&d_cubes_, sizeof(CubeRec) * cap));
+		HIPCHK(hipMalloc(&d_ub_, sizeof(float) * cap));
+		HIPCHK(hipMalloc(&d_lb_, sizeof(float) * cap));
+		HIPCHK(hipHostMalloc(&h_cubes_, sizeof(CubeRec) * cap));
+		HIPCHK(hipHostMalloc(&h_ub_, sizeof(float) * cap));
+		HIPCHK(hipHostMalloc(&h_lb_, sizeof(float) * cap));
+		cap_cubes_ = cap;
+	}
+	if (K > cap_rots_) {
+		size_t cap = std::max<size_t>(K, cap_rots_ * 2);
+		hipStreamSynchronize(stream_);
+		hipFree(d_rots_); hipHostFree(h_rots_);
+		HIPCHK(hipMalloc(&d_rots_, sizeof(Rot9) * cap));
+		HIPCHK(hipHostMalloc(&h_rots_, sizeof(Rot9) * cap));
+		cap_rots_ = cap;
+	}
+	size_t need = bounds_scratch_floats((int)std::max<size_t>(B, 1), (int)N_, nullptr, nullptr);
+	// the scratch need is not monotone in B (fewer cubes -> more point chunks): size for the worst case
+	size_t worst = (size_t)2 * kGroup * (size_t)(2048 + (cap_cubes_ + kGroup - 1) / kGroup + 64) * 2;
+	need = std::max(need, worst);
+	if (need > cap_scratch_) {
+		hipStreamSynchronize(stream_);
+		hipFree(d_scratch_);
+		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
+		cap_scratch_ = need;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------------
+void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s)
+{
+	size_t need = bounds_scratch_floats(B, (int)N_, nullptr, nullptr);
+	if (need > cap_scratch_) {
+		HIPCHK(hipDeviceSynchronize());
+		hipFree(d_scratch_);
+		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
+		cap_scratch_ = need;
+	}
+	HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
+	cnt_.bounds_launches++;
+}
+
+float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters)
+{
+	eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_);   // sizes the scratch
+	HIPCHK(hipStreamSynchronize(stream_));
+	HIPCHK(hipEventRecord(ev0_, stream_));
+	for (int i = 0; i < iters; i++) eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_);
+	HIPCHK(hipEventRecord(ev1_, stream_));
+	HIPCHK(hipEventSynchronize(ev1_));
+	float ms = 0.f;
+	HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+	return ms / (float)std::max(iters, 1);
+}
+
+void Engine::eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cubes, size_t B, float* ub, float* lb)
+{
+	if (B == 0) return;
+	for (size_t i = 0; i < B; i++)
+		if (cubes[i].rot < 0 || (size_t)cubes[i].rot >= K) throw std::invalid_argument("goicp: cube rotation index out of range");
+	ensure_batch(B, K);
+	std::memcpy(h_rots_, rots9, sizeof(Rot9) * K);
+	if (cubes != h_cubes_) std::memcpy(h_cubes_, cubes, sizeof(CubeRec) * B);
+	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * K, hipMemcpyHostToDevice, stream_));
+	HIPCHK(hipMemcpyAsync(d_cubes_, h_cubes_, sizeof(CubeRec) * B, hipMemcpyHostToDevice, stream_));
+	eval_bounds_dev(d_rots_, d_cubes_, (int)B, d_ub_, d_lb_, stream_);
+	HIPCHK(hipMemcpyAsync(h_ub_, d_ub_, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipMemcpyAsync(h_lb_, d_lb_, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	if (ub && ub != h_ub_) std::memcpy(ub, h_ub_, sizeof(float) * B);
+	if (lb && lb != h_lb_) std::memcpy(lb, h_lb_, sizeof(float) * B);
+	cnt_.cubes += (long long)B;
+}
+
+void Engine::eval_bounds(const float R[9], const float* cubes4, size_t B, int level, float* ub, float* lb)
+{
+	if (B == 0) return;
+	ensure_batch(B, 1);
+	const float coeff = rot_coeff(level);
+	for (size_t i = 0; i < B; i++) {
+		CubeRec& c = h_cubes_[i];
+		c.tx = cubes4[4 * i]; c.ty = cubes4[4 * i + 1]; c.tz = cubes4[4 * i + 2];
+		c.delta = (float)(kSQRT3 / 2.0 * (double)cubes4[4 * i + 3]);   // jly_goicp.cpp:263
+		c.coeff = coeff;
+		c.rot = 0;
+	}
+	eval_bounds_batch(R, 1, h_cubes_, B, ub, lb);
+}
+
+float Engine::eval_sse(const float R[9], const float t[3])
+{
+	// sum_i Distance(R p_i + t)^2 (jly_goicp.cpp:100-129): one cube with centre t, no radii
+	float cube[4] = {t[0], t[1], t[2], 0.f};
+	float ub = 0.f, lb = 0.f;
+	eval_bounds(R, cube, 1, -1, &ub, &lb);
+	cnt_.cubes -= 1;   // a score, not a BnB cube bound
+	return ub;
+}
+
+void Engine::dt_download(float* out)
+{
+	const size_t V = dt_.V;
+	if (!dt_.layout) {
+		HIPCHK(hipMemcpy(out, d_dt_, sizeof(float) * V * V * V, hipMemcpyDeviceToHost));
+		return;
+	}
+	const size_t VB = dt_.VB, nb = VB * VB * VB * 64;
+	std::vector<float> tmp(nb);
+	HIPCHK(hipMemcpy(tmp.data(), d_dt_, sizeof(float) * nb, hipMemcpyDeviceToHost));
+	for (size_t z = 0; z < V; z++)
+		for (size_t y = 0; y < V; y++)
+			for (size_t x = 0; x < V; x++) {
+				size_t b = ((z >> 2) * VB + (y >> 2)) * VB + (x >> 2);
+				out[(z * V + y) * V + x] = tmp[b * 64 + (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))];
+			}
+}
+
+void Engine::nn_query(const float* q, size_t n, int32_t* idx, float* d2)
+{
+	if (n == 0) return;
+	float* dq = nullptr; int32_t* di = nullptr; float* dd = nullptr;
+	HIPCHK(hipMalloc(&dq, sizeof(float) * 3 * n));
+	HIPCHK(hipMalloc(&di, sizeof(int32_t) * n));
+	HIPCHK(hipMalloc(&dd, sizeof(float) * n));
+	HIPCHK(hipMemcpyAsync(dq, q, sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream_));
+	HIPCHK(launch_nn_query(dq, (int)n, kd_, di, dd, stream_));
+	HIPCHK(hipMemcpyAsync(idx, di, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipMemcpyAsync(d2, dd, sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	hipFree(dq); hipFree(di); hipFree(dd);
+}
+
+void Engine::source_transformed(const float R[9], const float t[3], float* out)
+{
+	for (size_t i = 0; i < N_; i++) {
+		const float* p = &h_src_sorted_[4 * i];
+		float* o = out + 3 * (size_t)src_perm_[i];
+		o[0] = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+		o[1] = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+		o[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// ICP (ICP3D<float>::Run, jly_icp3d.hpp:181-295; IterativeClosestPoint3D::run, fgoicp/icp3d.cu:83-108)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct IcpState { float mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0}; };   // carried across iterations as the reference does
+
+// host part of one iteration: sums -> (R_, t_) -> composed pose
+void icp_update(const double s[16], size_t n, const float cq[3], const float cm[3], IcpState& st, float R[9], float t[3])
+{
+	const double nn = (double)n;
+	double alpha[3], beta[3];
+	for (int k = 0; k < 3; k++) {
+		double sum_q = s[k] + nn * (double)cq[k];
+		double sum_m = s[3 + k] + nn * (double)cm[k];
+		// jly_icp3d.hpp:244-263: the means are accumulated on top of the previous means and divided by n
+		st.mu_d[k] = (float)(((double)st.mu_d[k] + sum_q) / nn);
+		st.mu_m[k] = (float)(((double)st.mu_m[k] + sum_m) / nn);
+		alpha[k] = (double)st.mu_d[k] - (double)cq[k];
+		beta[k] = (double)st.mu_m[k] - (double)cm[k];
+	}
+	// H = sum (q - mu_d)(m - mu_m)^T from the pivoted sums
+	double H[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++)
+			H[3 * i + j] = s[6 + 3 * i + j] - alpha[i] * s[3 + j] - s[i] * beta[j] + nn * alpha[i] * beta[j];
+	for (int k = 0; k < 9; k++) H[k] = (double)(float)H[k];   // the reference holds H in float
+	float R_[9];
+	kabsch_rotation(H, R_);
+	float t_[3];
+	for (int i = 0; i < 3; i++) {
+		float acc = 0.f;
+		for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * st.mu_d[k];
+		t_[i] = st.mu_m[i] - acc;                       // t_ = mu_m - R_ mu_d
+	}
+	float Rn[9], tn[3];
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) {
+			float acc = 0.f;
+			for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * R[3 * k + j];
+			Rn[3 * i + j] = acc;                        // R <- R_ R
+		}
+		float acc = 0.f;
+		for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * t[k];
+		tn[i] = acc + t_[i];                            // t <- R_ t + t_
+	}
+	std::memcpy(R, Rn, sizeof(Rn));
+	std::memcpy(t, tn, sizeof(tn));
+}
+}  // namespace
+
+float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters_out)
+{
+	IcpState st;
+	float err = -1.f, err_new = 0.f;
+	int iter = 0;
+	Pose pose;
+	for (iter = 0; iter < max_iter; iter++) {
+		std::memcpy(pose.R, R, sizeof(pose.R));
+		std::memcpy(pose.t, t, sizeof(pose.t));
+		float cq[3];
+		for (int i = 0; i < 3; i++) cq[i] = R[3 * i] * src_centroid_[0] + R[3 * i + 1] * src_centroid_[1] + R[3 * i + 2] * src_centroid_[2] + t[i];
+		HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+		HIPCHK(hipMemcpyAsync(h_icp_out_, d_icp_out_, sizeof(double) * kIcpAcc, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipStreamSynchronize(stream_));
+		err_new = (float)h_icp_out_[15];
+		if (err > 0 && err - err_new < err_diff * (float)N_) break;    // jly_icp3d.hpp:255
+		err = err_new;
+		icp_update(h_icp_out_, N_, cq, model_centroid_, st, R, t);
+		if (cancel_.load()) { iter++; break; }
+	}
+	if (iters_out) *iters_out = iter;
+	cnt_.icp_iters += iter;
+	cnt_.icp_runs++;
+	return err_new;
+}
+
+float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
+{
+	Pose pose;
+	std::memcpy(pose.R, R, sizeof(pose.R));
+	std::memcpy(pose.t, t, sizeof(pose.t));
+	float cq[3] = {0, 0, 0};
+	HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	HIPCHK(hipEventRecord(ev0_, stream_));
+	for (int i = 0; i < iters; i++)
+		HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+	HIPCHK(hipEventRecord(ev1_, stream_));
+	HIPCHK(hipEventSynchronize(ev1_));
+	float ms = 0.f;
+	HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+	return ms / (float)std::max(iters, 1);
+}
+
+void Engine::icp_step()
+{
+	// one iteration from the current step pose, fresh means, standard Kabsch (icp_kernel.cu:219-279)
+	IcpState st;
+	Pose pose;
+	std::memcpy(pose.R, stepR_, sizeof(pose.R));
+	std::memcpy(pose.t, stepT_, sizeof(pose.t));
+	float cq[3];
+	for (int i = 0; i < 3; i++) cq[i] = stepR_[3 * i] * src_centroid_[0] + stepR_[3 * i + 1] * src_centroid_[1] + stepR_[3 * i + 2] * src_centroid_[2] + stepT_[i];
+	HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+	HIPCHK(hipMemcpyAsync(h_icp_out_, d_icp_out_, sizeof(double) * kIcpAcc, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	icp_update(h_icp_out_, N_, cq, model_centroid_, st, stepR_, stepT_);
+	cnt_.icp_iters++;
+	std::lock_guard<std::mutex> lk(mtx_);
+	std::memcpy(snap_.curR, stepR_, sizeof(stepR_));
+	std::memcpy(snap_.curT, stepT_, sizeof(stepT_));
+	std::memcpy(snap_.optR, stepR_, sizeof(stepR_));
+	std::memcpy(snap_.optT, stepT_, sizeof(stepT_));
+	snap_.best_sse = (float)h_icp_out_[15];
+	snap_.counters = cnt_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inner (translation) BnB, batched across searches
+// ------------------------------------------------------------------------------------------------
+void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
+{
+	const int K = std::max(1, p_.trans_batch);
+	const size_t nrot = rots.size();
+	for (auto* s : searches)
+		if (s->rot_slot < 0 || (size_t)s->rot_slot >= nrot) throw std::logic_error("goicp: rotation slot out of range");
+	bool rots_uploaded = false;
+	while (true) {
+		size_t B = 0;
+		for (auto* s : searches) {
+			s->parents.clear();
+			if (s->done) continue;
+			while ((int)s->parents.size() < K && !s->pq.empty()) {
+				const Node n = s->pq.top();
+				if (s->best - n.lb < sse_thresh_) {           // jly_goicp.cpp:257
+					if (s->parents.empty()) { s->pq.pop(); s->pops++; s->done = true; }
+					break;
+				}
+				s->pq.pop();
+				s->pops++;
+				s->parents.push_back(n);
+			}
+			if (s->parents.empty()) { s->done = true; continue; }
+			B += 8 * s->parents.size();
+		}
+		if (B == 0) break;
+		ensure_batch(B, nrot);
+		size_t o = 0;
+		for (auto* s : searches) {
+			for (const Node& par : s->parents) {
+				const float w = par.w / 2;                                  // :262
+				const float delta = (float)(kSQRT3 / 2.0 * (double)w);     // :263
+				for (int j = 0; j < 8; j++) {
+					float cx = par.x + (j & 1) * w, cy = par.y + (j >> 1 & 1) * w, cz = par.z + (j >> 2 & 1) * w;
+					CubeRec& c = h_cubes_[o++];
+					c.tx = cx + w / 2; c.ty = cy + w / 2; c.tz = cz + w / 2;   // :271-273
+					c.delta = delta; c.coeff = s->coeff; c.rot = s->rot_slot;
+				}
+			}
+		}
+		if (!rots_uploaded) {
+			std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
+			HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * nrot, hipMemcpyHostToDevice, stream_));
+			rots_uploaded = true;
+		}
+		HIPCHK(hipMemcpyAsync(d_cubes_, h_cubes_, sizeof(CubeRec) * B, hipMemcpyHostToDevice, stream_));
+		eval_bounds_dev(d_rots_, d_cubes_, (int)B, d_ub_, d_lb_, stream_);
+		HIPCHK(hipMemcpyAsync(h_ub_, d_ub_, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(h_lb_, d_lb_, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipStreamSynchronize(stream_));
+		o = 0;
+		for (auto* s : searches) {
+			for (const Node& par : s->parents) {
+				Node c{};
+				c.w = par.w / 2;
+				for (int j = 0; j < 8; j++, o++) {
+					c.x = par.x + (j & 1) * c.w; c.y = par.y + (j >> 1 & 1) * c.w; c.z = par.z + (j >> 2 & 1) * c.w;
+					const float ub = h_ub_[o], lb = h_lb_[o];
+					s->cubes++;
+					if (ub < s->best) { s->best = ub; s->best_node = c; s->improved = true; }   // :319-324
+					if (lb >= s->best) continue;                                                  // :327
+					c.ub = ub; c.lb = lb;
+					s->pq.push(c);
+				}
+			}
+		}
+		if (cancel_.load()) break;
+	}
+}
+
+float Engine::inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c)
+{
+	std::vector<Rot9> rots(1);
+	std::memcpy(rots[0].r, R, sizeof(float) * 9);
+	InnerSearch s;
+	s.rot_slot = 0;
+	s.coeff = rot_coeff(level);
+	s.best = incumbent;
+	s.pq.push(Node{-0.5f, -0.5f, -0.5f, 1.0f, 0.f, 0.f, 0});   // jly_goicp.cpp:50-53
+	std::vector<InnerSearch*> v{&s};
+	run_inner(v, rots);
+	if (best_node && s.improved) { best_node[0] = s.best_node.x; best_node[1] = s.best_node.y; best_node[2] = s.best_node.z; best_node[3] = s.best_node.w; }
+	cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
+	if (c) { c->trans_pops += s.pops; c->cubes += s.cubes; c->inner_calls++; }
+	return s.best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// outer (rotation) BnB
+// ------------------------------------------------------------------------------------------------
+void Engine::publish(bool finished)
+{
+	std::lock_guard<std::mutex> lk(mtx_);
+	std::memcpy(snap_.optR, optR_, sizeof(optR_)); std::memcpy(snap_.optT, optT_, sizeof(optT_));
+	std::memcpy(snap_.curR, curR_, sizeof(curR_)); std::memcpy(snap_.curT, curT_, sizeof(curT_));
+	snap_.best_sse = opt_err_;
+	snap_.finished = finished ? 1 : 0;
+	snap_.counters = cnt_;
+	snap_.dt_build_ms = dt_build_ms_;
+	snap_.register_ms = register_ms_;
+}
+
+Result Engine::poll()
+{
+	std::lock_guard<std::mutex> lk(mtx_);
+	return snap_;
+}
+
+void Engine::adopt(float err, const float R[9], const float t[3])
+{
+	opt_err_ = err;
+	std::memcpy(optR_, R, sizeof(optR_));
+	std::memcpy(optT_, t, sizeof(optT_));
+}
+
+float Engine::icp_from(float R[9], float t[3])
+{
+	// GoICP::ICP (jly_goicp.cpp:93-132): ICP3D::Run, then re-score with the DT
+	int it = 0;
+	icp_run(R, t, p_.icp_max_iter, icp_err_diff_, &it);
+	return eval_sse(R, t);
+}
+
+void Engine::offer_global_best(float sse, const float R[9], const float t[3])
+{
+	if (sse < opt_err_) {
+		adopt(sse, R, t);
+		// drop queued nodes that can no longer win (jly_goicp.cpp:533-543)
+		std::priority_queue<Node> nq;
+		while (!queue_.empty()) {
+			Node n = queue_.top(); queue_.pop();
+			if (n.lb < opt_err_) nq.push(n); else break;
+		}
+		queue_.swap(nq);
+		if (opt_err_ < sse_thresh_) early_exit_ = true;
+		publish(false);
+	}
+}
+
+void Engine::register_begin()
+{
+	cancel_.store(false);
+	early_exit_ = converged_ = false;
+	cnt_ = Counters{};
+	while (!queue_.empty()) queue_.pop();
+	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	const float Z[3] = {0, 0, 0};
+	// initial error (jly_goicp.cpp:357-372) and initial ICP (:375-391)
+	opt_err_ = eval_sse(I, Z);
+	std::memcpy(optR_, I, sizeof(I)); std::memcpy(optT_, Z, sizeof(Z));
+	float R[9], t[3];
+	std::memcpy(R, I, sizeof(I)); std::memcpy(t, Z, sizeof(Z));
+	float e = icp_from(R, t);
+	if (e < opt_err_) adopt(e, R, t);
+	std::memcpy(curR_, optR_, sizeof(optR_)); std::memcpy(curT_, optT_, sizeof(optT_));
+	if (p_.verbose) std::fprintf(stderr, "[goicp] init error %.6g (after ICP)\n", opt_err_);
+
+	Node root{(float)-kPI, (float)-kPI, (float)-kPI, (float)(2 * kPI), 0.f, 0.f, 0};   // jly_goicp.cpp:44-48
+	if (world_ <= 1) {
+		queue_.push(root);
+	} else {
+		// shard: expand the root two levels (64 cubes) and deal them round-robin to the ranks; the
+		// parents' bounds are 0, so nothing is lost
+		int k = 0;
+		for (int a = 0; a < 8; a++) {
+			Node c1 = root; c1.w = root.w / 2; c1.l = 1;
+			c1.x = root.x + (a & 1) * c1.w; c1.y = root.y + (a >> 1 & 1) * c1.w; c1.z = root.z + (a >> 2 & 1) * c1.w;
+			for (int b = 0; b < 8; b++, k++) {
+				Node c2 = c1; c2.w = c1.w / 2; c2.l = 2;
+				c2.x = c1.x + (b & 1) * c2.w; c2.y = c1.y + (b >> 1 & 1) * c2.w; c2.z = c1.z + (b >> 2 & 1) * c2.w;
+				if (k % world_ == rank_) queue_.push(c2);
+			}
+		}
+	}
+	publish(false);
+}
+
+void Engine::process_parent(const Node& parent)
+{
+	struct Child { Node node; float R[9]; };
+	std::vector<Child> kids;
+	Node c{};
+	c.w = parent.w / 2;          // jly_goicp.cpp:427-428
+	c.l = parent.l + 1;
+	for (int j = 0; j < 8; j++) {
+		c.x = parent.x + (j & 1) * c.w; c.y = parent.y + (j >> 1 & 1) * c.w; c.z = parent.z + (j >> 2 & 1) * c.w;
+		float v1 = c.x + c.w / 2, v2 = c.y + c.w / 2, v3 = c.z + c.w / 2;
+		// pi-ball cull (:443): float sqrt, double subtraction and comparison
+		if ((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - kSQRT3 * (double)c.w / 2 > kPI) continue;
+		Child k;
+		k.node = c;
+		rodrigues(v1, v2, v3, k.R);
+		kids.push_back(k);
+	}
+	if (kids.empty()) return;
+	std::vector<Rot9> rots(kids.size());
+	for (size_t i = 0; i < kids.size(); i++) std::memcpy(rots[i].r, kids[i].R, sizeof(float) * 9);
+	const Node troot{-0.5f, -0.5f, -0.5f, 1.0f, 0.f, 0.f, 0};
+
+	auto handle_ub = [&](Child& k, InnerSearch& s) -> bool {   // jly_goicp.cpp:495-544; returns true on early exit
+		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
+		k.node.ub = s.best;
+		std::memcpy(curR_, k.R, sizeof(curR_));
+		if (s.improved) { curT_[0] = s.best_node.x + s.best_node.w / 2; curT_[1] = s.best_node.y + s.best_node.w / 2; curT_[2] = s.best_node.z + s.best_node.w / 2; }
+		if (!(s.best < opt_err_) || !s.improved) return false;
+		float t[3] = {s.best_node.x + s.best_node.w / 2, s.best_node.y + s.best_node.w / 2, s.best_node.z + s.best_node.w / 2};
+		adopt(s.best, k.R, t);
+		float R[9], ti[3];
+		std::memcpy(R, k.R, sizeof(R)); std::memcpy(ti, t, sizeof(ti));
+		float e = icp_from(R, ti);
+		if (e < opt_err_) adopt(e, R, ti);
+		if (p_.verbose) std::fprintf(stderr, "[goicp] rank %d  error* %.6g (ub %.6g, level %d)\n", rank_, opt_err_, s.best, k.node.l);
+		publish(false);
+		if (opt_err_ < sse_thresh_) { early_exit_ = true; return true; }   // :527
+		std::priority_queue<Node> nq;                                       // :533-543
+		while (!queue_.empty()) {
+			Node n = queue_.top(); queue_.pop();
+			if (n.lb < opt_err_) nq.push(n); else break;
+		}
+		queue_.swap(nq);
+		return false;
+	};
+	auto handle_lb = [&](Child& k, InnerSearch& s) {           // :551-562
+		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
+		if (s.best >= opt_err_) return;
+		k.node.lb = s.best;
+		queue_.push(k.node);
+	};
+	auto fresh = [&](size_t slot, float coeff) {
+		InnerSearch s;
+		s.rot_slot = (int)slot; s.coeff = coeff; s.best = opt_err_;
+		s.pq.push(troot);
+		return s;
+	};
+
+	if (p_.wide_children) {
+		// all children's upper-bound searches in lockstep, then all lower-bound searches
+		std::vector<InnerSearch> ubs, lbs;
+		ubs.reserve(kids.size()); lbs.reserve(kids.size());
+		std::vector<InnerSearch*> ptr;
+		for (size_t i = 0; i < kids.size(); i++) { ubs.push_back(fresh(i, 0.f)); }
+		for (auto& s : ubs) ptr.push_back(&s);
+		run_inner(ptr, rots);
+		for (size_t i = 0; i < kids.size(); i++)
+			if (handle_ub(kids[i], ubs[i])) return;
+		ptr.clear();
+		for (size_t i = 0; i < kids.size(); i++) { lbs.push_back(fresh(i, rot_coeff(kids[i].node.l))); }
+		for (auto& s : lbs) ptr.push_back(&s);
+		run_inner(ptr, rots);
+		for (size_t i = 0; i < kids.size(); i++) handle_lb(kids[i], lbs[i]);
+	} else {
+		for (size_t i = 0; i < kids.size(); i++) {
+			InnerSearch u = fresh(i, 0.f);
+			std::vector<InnerSearch*> p1{&u};
+			run_inner(p1, rots);
+			if (handle_ub(kids[i], u)) return;
+			InnerSearch l = fresh(i, rot_coeff(kids[i].node.l));
+			std::vector<InnerSearch*> p2{&l};
+			run_inner(p2, rots);
+			handle_lb(kids[i], l);
+			if (cancel_.load()) return;
+		}
+	}
+}
+
+StepStatus Engine::register_step(int max_rot_pops)
+{
+	int pops = 0;
+	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
+		Node parent = queue_.top();
+		queue_.pop();
+		cnt_.rot_pops++;
+		pops++;
+		if ((opt_err_ - parent.lb) <= sse_thresh_) {          // jly_goicp.cpp:416
+			// single rank: global convergence.  sharded: this rank's frontier can no longer improve
+			converged_ = true;
+			break;
+		}
+		process_parent(parent);
+		publish(false);
+	}
+	StepStatus st{};
+	st.early_exit = early_exit_ ? 1 : 0;
+	st.finished = (early_exit_ || converged_ || queue_.empty() || cancel_.load()) ? 1 : 0;
+	st.best_sse = opt_err_;
+	st.frontier_lb = (queue_.empty() || converged_ || early_exit_) ? std::numeric_limits<float>::infinity() : queue_.top().lb;
+	st.rot_pops = cnt_.rot_pops;
+	return st;
+}
+
+void Engine::register_end()
+{
+	publish(true);
+}
+
+void Engine::run()
+{
+	double t0 = now_ms();
+	register_begin();
+	while (true) {
+		StepStatus st = register_step(64);
+		if (st.finished) break;
+	}
+	register_ms_ = now_ms() - t0;
+	register_end();
+}
+
+}  // namespace goicp

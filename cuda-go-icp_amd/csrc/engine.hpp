@@ -1,0 +1,163 @@
+// Host side of the MI355X Go-ICP engine: owns the HBM-resident clouds / distance transform /
+// k-d tree, drives the HIP kernels, and runs the branch-and-bound search and the ICP loop.
+// Semantics follow the reference CPU Go-ICP path (src/goicp/jly_goicp.cpp) behind the surface of
+// the reference GPU classes (src/fgoicp/fgoicp.hpp, registration.hpp, icp3d.hpp).
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "device.hpp"
+
+namespace goicp {
+
+struct Params {
+	int dt_size = 300;            // jly_goicp.cpp:56
+	double dt_expand = 2.0;       // jly_goicp.cpp:57
+	float mse_threshold = 1e-3f;  // Config::mse_threshold (common.cpp:62)
+	int dt_layout = 1;            // 0 linear, 1 bricked 4x4x4
+	int device = -1;              // -1: current HIP device
+	int trans_batch = 16;         // translation nodes expanded per inner search per launch (1 = reference order)
+	int wide_children = 1;        // run the 8 rotation children's inner searches concurrently (0 = reference order)
+	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
+	int verbose = 0;
+	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
+};
+
+struct Counters {
+	long long rot_pops = 0, trans_pops = 0, cubes = 0, inner_calls = 0, icp_runs = 0, icp_iters = 0;
+	long long bounds_launches = 0;
+};
+
+// what the viewer polls (fgoicp.hpp:34,67-69; goicp_kernel.cu:161-177)
+struct Result {
+	float optR[9], optT[3], curR[9], curT[3];
+	float best_sse;
+	int finished;
+	Counters counters;
+	double dt_build_ms, register_ms;
+};
+
+// corner + width node, ordered like jly_goicp.h:44-72 (smaller lb first, then the wider cube)
+struct Node {
+	float x, y, z, w, ub, lb;
+	int l;
+	friend bool operator<(const Node& a, const Node& b)
+	{
+		if (a.lb != b.lb) return a.lb > b.lb;
+		return a.w < b.w;
+	}
+};
+
+struct StepStatus {
+	int finished;        // this rank has nothing left (queue empty, converged, or early exit)
+	int early_exit;      // best_sse < sse_threshold (jly_goicp.cpp:527): every rank may stop
+	float best_sse;
+	float frontier_lb;   // min lb over this rank's queue (+inf when empty)
+	long long rot_pops;
+};
+
+class Engine {
+public:
+	Engine(const Params& p, const float* target_xyz, size_t M, const float* source_xyz, size_t N);
+	~Engine();
+	Engine(const Engine&) = delete;
+
+	// ---- operators (all synchronous) ----
+	// Registration::compute_sse_error(RotNode&, vector<TransNode>&, fix_rot, StreamPool&) with the CPU
+	// path's semantics: cubes = B x {centre xyz, child width}; level < 0 => no rotation radius.
+	void eval_bounds(const float R[9], const float* cubes4, size_t B, int level, float* ub, float* lb);
+	void eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cubes, size_t B, float* ub, float* lb);
+	void eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s);
+	float time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters);
+	float eval_sse(const float R[9], const float t[3]);
+	float inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c);
+	float icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters);
+	float time_icp_pass(const float R[9], const float t[3], int iters);
+	void nn_query(const float* q_xyz, size_t n, int32_t* idx, float* d2);
+	void icp_step();   // one ICP iteration on the engine's current pose (ICP::kdTreeGPUStep)
+
+	// ---- registration ----
+	void run();                                  // FastGoICP::run / GoICP::Register
+	void cancel() { cancel_.store(true); }
+	Result poll();
+	// stepped form for multi-GPU sharding
+	void set_shard(int rank, int world) { rank_ = rank; world_ = world; }
+	void register_begin();
+	StepStatus register_step(int max_rot_pops);
+	void offer_global_best(float sse, const float R[9], const float t[3]);   // result of the min all-reduce
+	void register_end();
+
+	// ---- inspection ----
+	const DtDesc& dt() const { return dt_; }
+	void dt_download(float* grid_linear);        // V^3, [z][y][x]
+	size_t n_source() const { return N_; }
+	size_t n_target() const { return M_; }
+	float sse_threshold() const { return sse_thresh_; }
+	float rot_coeff(int level) const;
+	hipStream_t stream() const { return stream_; }
+	const float4* d_source() const { return d_src_; }
+	void source_transformed(const float R[9], const float t[3], float* out_xyz);  // original order
+
+private:
+	struct InnerSearch;
+	void ensure_batch(size_t B, size_t K);
+	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
+	void process_parent(const Node& parent);
+	void adopt(float err, const float R[9], const float t[3]);
+	float icp_from(float R[9], float t[3]);
+	void publish(bool finished);
+
+	Params p_;
+	size_t M_ = 0, N_ = 0;
+	float sse_thresh_ = 0.f, icp_err_diff_ = 0.f;
+	int rank_ = 0, world_ = 1;
+
+	hipStream_t stream_ = nullptr;
+	hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+	float4* d_src_ = nullptr;         // N  (x,y,z,|p|), Morton order
+	std::vector<int32_t> src_perm_;   // sorted position -> original index
+	std::vector<float> h_src_sorted_; // N*4
+	float src_centroid_[3] = {0, 0, 0}, model_centroid_[3] = {0, 0, 0};
+	DtDesc dt_{};
+	float* d_dt_ = nullptr;
+	// k-d tree
+	KdDesc kd_{};
+	float2* d_kd_nodes_ = nullptr; float4* d_kd_pts_ = nullptr; int32_t* d_kd_leaf_ = nullptr;
+	// bounds staging
+	size_t cap_cubes_ = 0, cap_rots_ = 0, cap_scratch_ = 0;
+	CubeRec* d_cubes_ = nullptr; CubeRec* h_cubes_ = nullptr;
+	Rot9* d_rots_ = nullptr; Rot9* h_rots_ = nullptr;
+	float* d_ub_ = nullptr; float* d_lb_ = nullptr; float* h_ub_ = nullptr; float* h_lb_ = nullptr;
+	float* d_scratch_ = nullptr;
+	// icp staging
+	float* d_icp_partials_ = nullptr; double* d_icp_out_ = nullptr; double* h_icp_out_ = nullptr;
+	// nn query staging grows on demand
+	float rot_coeff_[20];
+
+	// search state
+	std::priority_queue<Node> queue_;
+	float opt_err_ = 1e10f;
+	float optR_[9], optT_[3], curR_[9], curT_[3];
+	bool early_exit_ = false, converged_ = false;
+	Counters cnt_;
+	std::atomic<bool> cancel_{false};
+	std::mutex mtx_;
+	Result snap_{};
+	double dt_build_ms_ = 0, register_ms_ = 0;
+	// icp_step state
+	float stepR_[9], stepT_[3];
+};
+
+// ---- host utilities (config_io.cpp, kdtree.cpp) ----
+struct KdHost {
+	std::vector<float2> nodes; std::vector<float4> pts; std::vector<int32_t> leaf_start; int L = 1;
+};
+void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
+void kabsch_rotation(const double H[9], float R[9]);   // R_ = V diag(1,1,det(V U^T)) U^T (jly_icp3d.hpp:268-285)
+void rodrigues(float v1, float v2, float v3, float R[9]);   // jly_goicp.cpp:449-467
+
+}  // namespace goicp

@@ -1,0 +1,212 @@
+/* goicp_mi355.h -- C ABI of libgoicp_mi355.so, the MI355X-native (gfx950, HIP) Go-ICP engine.
+ *
+ * Drop-in boundary for the hot path of zjsun1017/CUDA-Go-ICP: BnB cube-bound evaluation, the
+ * inner ICP loop and the rotation-cube search.  Every entry point names the reference interface
+ * it replaces (paths relative to the reference checkout).  Plain pointers and sizes only; all
+ * matrices are row-major float[9]; clouds are packed float xyz triples.
+ *
+ * Conventions
+ *   - every function returns GOICP_OK (0) or a negative goicp_status; the message of the last
+ *     failure on the calling thread is available from goicp_last_error().
+ *   - handles are opaque; one handle per host thread, except goicp_poll()/goicp_cancel(), which
+ *     are safe concurrently with goicp_register() (the reference's viewer polls the worker,
+ *     src/goicp_kernel.cu:161-177).
+ *   - output buffers are caller-owned unless a matching *_free() exists.
+ *   - there is NO CPU fallback: goicp_create() fails with GOICP_ERR_NO_DEVICE without a GPU.
+ *   - numerical contract: per-point arithmetic is bit-identical to the reference CPU path
+ *     (src/goicp/); sums are tree reductions, so bounds agree to ~1e-5 relative.
+ */
+#ifndef GOICP_MI355_H
+#define GOICP_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOICP_ABI_VERSION 1
+
+typedef enum goicp_status {
+	GOICP_OK = 0,
+	GOICP_ERR_INVALID = -1,    /* bad argument */
+	GOICP_ERR_IO = -2,         /* file missing / unreadable / malformed  (reference: std::runtime_error, src/common.cpp:139-142,196-199,210,226) */
+	GOICP_ERR_CONFIG = -3,     /* TOML parse error / missing info.description (src/common.cpp:28-40) */
+	GOICP_ERR_NO_DEVICE = -4,  /* no HIP device: the product never computes on the CPU */
+	GOICP_ERR_DEVICE = -5,     /* HIP runtime failure (reference: exit(EXIT_FAILURE), src/kernel.cu:29-38) */
+	GOICP_ERR_INTERNAL = -6
+} goicp_status;
+
+const char* goicp_last_error(void);
+int goicp_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Config  -- replaces class Config (src/common.h:133-180, src/common.cpp:12-77).
+ * Same keys, defaults and clamps.  Keys the reference declares but never parses
+ * ([params.rotation], [params.translation], search_depth: src/common.h:157-169) are read here too.
+ * ------------------------------------------------------------------------------------------- */
+#define GOICP_PATH_MAX 1024
+typedef struct goicp_config {
+	int32_t mode;                 /* 0 ICP CPU, 1 ICP GPU, 2 ICP k-d tree GPU, 3 Go-ICP CPU, 4 Go-ICP GPU (src/common.h:7-11) */
+	int32_t trim;
+	float subsample;              /* clamped to [0,1]      (src/common.cpp:63) */
+	float mse_threshold;          /* clamped to >= 1e-10   (src/common.cpp:64) */
+	float resize;
+	char target[GOICP_PATH_MAX];
+	char source[GOICP_PATH_MAX];
+	char output[GOICP_PATH_MAX];
+	char visualization[GOICP_PATH_MAX];
+	float viz_theta, viz_phi;
+	int32_t viz_spin_after_finish;
+	float rot_min[3], rot_max[3];     /* degrees */
+	int32_t rot_search_depth;
+	float trans_min[3], trans_max[3];
+	int32_t trans_search_depth;
+	char description[GOICP_PATH_MAX];
+} goicp_config;
+
+int goicp_config_load(const char* toml_path, goicp_config* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cloud loader -- replaces load_cloud / load_cloud_ply / load_cloud_txt (src/common.cpp:79-228):
+ * ".ply" (ascii or binary_little_endian, element vertex with float x,y,z, other properties and
+ * elements skipped) or ".txt" ("N" then N lines "x y z").  Points are multiplied by `resize`;
+ * `subsample` keeps each point with that probability, capped at floor(N*subsample).
+ * seed = 0 reproduces the reference's non-deterministic std::random_device seeding.
+ * ------------------------------------------------------------------------------------------- */
+int goicp_cloud_load(const char* path, float subsample, float resize, uint64_t seed, float** xyz, size_t* n);
+void goicp_cloud_free(float* xyz);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine -- replaces icp::FastGoICP + icp::Registration + icp::IterativeClosestPoint3D
+ * (src/fgoicp/fgoicp.hpp:11-69, registration.hpp:44-98, icp3d.hpp:9-41) with the CPU path's
+ * semantics (GoICP, src/goicp/jly_goicp.h:84-142).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct goicp_engine* goicp_handle;
+
+typedef struct goicp_params {
+	int32_t dt_size;         /* DT grid side, reference 300 (src/goicp/jly_goicp.cpp:56) */
+	double dt_expand;        /* bbox expand factor, reference 2.0 (src/goicp/jly_goicp.cpp:57) */
+	float mse_threshold;     /* SSE threshold = mse_threshold * N (src/goicp/jly_goicp.cpp:208, src/fgoicp/fgoicp.hpp:23) */
+	int32_t dt_layout;       /* 0 linear [z][y][x]; 1 bricked 4x4x4 (default) */
+	int32_t device;          /* HIP device ordinal, -1 = current */
+	int32_t trans_batch;     /* translation nodes expanded per search per launch; 1 = reference visit order */
+	int32_t wide_children;   /* 1: the 8 rotation children's inner searches run concurrently; 0 = reference order */
+	int32_t icp_max_iter;    /* reference 10000 (src/goicp/jly_icp3d.hpp:114) */
+	int32_t verbose;
+	int32_t morton_sort;     /* 1: source cloud kept in Morton order on the device */
+} goicp_params;
+
+void goicp_params_default(goicp_params* p);
+
+/* FastGoICP::FastGoICP(pct, pcs, mse_threshold, mtx) (src/fgoicp/fgoicp.hpp:14-28) + Registration ctor
+ * (registration.hpp:66-80) + GoICP::BuildDT/Initialize (src/goicp/jly_goicp.cpp:75-90,134-209):
+ * uploads both clouds, builds the distance transform (exact EDT, on the GPU) and the k-d tree. */
+int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_target,
+                 const float* source_xyz, size_t n_source, goicp_handle* out);
+int goicp_destroy(goicp_handle h);
+
+/* DT3D geometry (src/goicp/jly_3ddt.h:100-111) and the grid itself ([z][y][x], V^3 floats) */
+int goicp_dt_info(goicp_handle h, int32_t* V, double* scale, double origin_xyz[3]);
+int goicp_dt_download(goicp_handle h, float* grid);
+
+/* ---- bounds operator ------------------------------------------------------------------------
+ * Registration::compute_sse_error(RotNode&, std::vector<TransNode>&, bool fix_rot, StreamPool&)
+ * (src/fgoicp/registration.hpp:97, registration.cu:88-151) == the inner body of GoICP::InnerBnB
+ * (src/goicp/jly_goicp.cpp:262-315).  cubes: B x {centre x,y,z, child width w}.
+ * level < 0  <=> fix_rot (no rotation uncertainty radius); otherwise the radii of rotation level
+ * `level` (maxRotDis[level], src/goicp/jly_goicp.cpp:148-160) are subtracted. */
+int goicp_eval_bounds(goicp_handle h, const float R[9], const float* cubes, size_t B, int32_t level,
+                      float* ub, float* lb);
+
+/* batched form: K rotations, B cube records (24 bytes each), each naming its rotation */
+typedef struct goicp_cube {
+	float tx, ty, tz;  /* cube centre */
+	float delta;       /* translation uncertainty radius sqrt(3)/2*w (src/goicp/jly_goicp.cpp:263) */
+	float coeff;       /* rotation uncertainty coefficient (goicp_rot_coeff(level)), 0 for fix_rot */
+	int32_t rot;       /* index into rots */
+} goicp_cube;
+int goicp_eval_bounds_batch(goicp_handle h, const float* rots /* K x 9 */, size_t K,
+                            const goicp_cube* cubes, size_t B, float* ub, float* lb);
+/* device-resident form (no host copies): all four pointers are device pointers; stream = a
+ * hipStream_t (NULL = the engine's own stream); asynchronous. */
+int goicp_eval_bounds_device(goicp_handle h, const void* d_rots, const void* d_cubes, size_t B,
+                             void* d_ub, void* d_lb, void* stream);
+/* average duration (ms, HIP events on the launch stream) of `iters` back-to-back launches */
+int goicp_time_bounds_device(goicp_handle h, const void* d_rots, const void* d_cubes, size_t B,
+                             void* d_ub, void* d_lb, int32_t iters, float* ms_per_launch);
+float goicp_rot_coeff(goicp_handle h, int32_t level);
+float goicp_trans_delta(float child_width);
+/* angle-axis vector (a rotation-cube centre) -> rotation matrix, float arithmetic in the order of
+ * GoICP::OuterBnB (src/goicp/jly_goicp.cpp:449-467); host-side helper */
+void goicp_rodrigues(const float v[3], float R[9]);
+
+/* Registration::compute_sse_error(glm::mat3 R, glm::vec3 t) (src/fgoicp/registration.hpp:96) scored
+ * with the DT as GoICP::ICP does (src/goicp/jly_goicp.cpp:100-129). */
+int goicp_eval_sse(goicp_handle h, const float R[9], const float t[3], float* sse);
+
+/* FastGoICP::branch_and_bound_R3(rnode, fix_rot) (src/fgoicp/fgoicp.cpp:107-181) == GoICP::InnerBnB
+ * (src/goicp/jly_goicp.cpp:227-340).  best_node = {corner x,y,z, width}, written only on improvement. */
+typedef struct goicp_counters {
+	int64_t rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters, bounds_launches;
+} goicp_counters;
+int goicp_inner_bnb(goicp_handle h, const float R[9], int32_t level, float incumbent, float* value,
+                    float best_node[4], goicp_counters* counters);
+
+/* IterativeClosestPoint3D::run (src/fgoicp/icp3d.hpp:30-35, icp3d.cu:83-108) == ICP3D<float>::Run
+ * (src/goicp/jly_icp3d.hpp:181-295).  R,t in/out; err = sum of squared NN distances of the last pass. */
+int goicp_icp_run(goicp_handle h, float R[9], float t[3], int32_t max_iter, float err_diff,
+                  float* err, int32_t* iters);
+/* average duration (ms) of one ICP correspondence pass (NN + sums) at the given pose */
+int goicp_time_icp_pass(goicp_handle h, const float R[9], const float t[3], int32_t iters, float* ms_per_pass);
+
+/* kernKDSearchNearest (src/icp_kernel.cu:146-157) / kernFindNearestNeighbor (src/fgoicp/icp3d.cu:13-30):
+ * exact 1-NN of n query points in the target; ties -> lowest target index. */
+int goicp_nn_query(goicp_handle h, const float* query_xyz, size_t n, int32_t* index, float* dist_sq);
+
+/* ICP::kdTreeGPUStep / ICP::naiveGPUStep (src/icp_kernel.h:9-13, icp_kernel.cu:176-279): ONE ICP
+ * iteration from the engine's current step pose (identity after create); the accumulated pose is
+ * visible through goicp_poll().curR/curT. */
+int goicp_icp_step(goicp_handle h);
+
+/* FastGoICP::run() (src/fgoicp/fgoicp.cpp:9-30) == GoICP::Register() (src/goicp/jly_goicp.cpp:569-585).
+ * Blocking; intended for a worker thread. */
+int goicp_register(goicp_handle h);
+int goicp_cancel(goicp_handle h);      /* the reference's global `goicp_finished` flag (src/goicp/jly_goicp.cpp:400) */
+
+/* Result API: FastGoICP::{get_best_error(), optR, optT, curR, curT, finished} (src/fgoicp/fgoicp.hpp:34,67-69),
+ * read by ICP::goicpGPUStep (src/goicp_kernel.cu:161-177).  A consistent snapshot; thread-safe. */
+typedef struct goicp_result {
+	float optR[9], optT[3];
+	float curR[9], curT[3];
+	float best_sse;
+	int32_t finished;
+	goicp_counters counters;
+	double dt_build_ms, register_ms;
+} goicp_result;
+int goicp_poll(goicp_handle h, goicp_result* out);
+/* the output.toml the reference's configs promise (test/bunny_goicp.toml:12) but never write */
+int goicp_result_write_toml(goicp_handle h, const char* path);
+/* source cloud under (R,t), original point order (what src/goicp_kernel.cu:181-193 draws) */
+int goicp_transform_source(goicp_handle h, const float R[9], const float t[3], float* out_xyz);
+
+/* ---- multi-GPU: rotation cubes sharded over ranks (new; the reference is single-GPU) -----------
+ * Each rank owns every world-th cube of the 64 level-2 rotation cubes and runs its own best-first
+ * search; between steps the caller min-all-reduces best_sse (and broadcasts the winner's R|t) and
+ * feeds the result back with goicp_offer_best(). */
+typedef struct goicp_step_status {
+	int32_t finished, early_exit;
+	float best_sse, frontier_lb;
+	int64_t rot_pops;
+} goicp_step_status;
+int goicp_set_shard(goicp_handle h, int32_t rank, int32_t world);
+int goicp_register_begin(goicp_handle h);
+int goicp_register_step(goicp_handle h, int32_t max_rot_pops, goicp_step_status* out);
+int goicp_offer_best(goicp_handle h, float sse, const float R[9], const float t[3]);
+int goicp_register_end(goicp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOICP_MI355_H */

@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libgoicp_mi355.so), against
+ (1) the committed golden vectors produced by the real reference CPU Go-ICP, and
+ (2) the CPU oracle (oracle/goicp_oracle.c) on the same seeded inputs.
+Tolerances are SURVEY.md 8(c)'s and are written next to each assertion.
+"""
+import numpy as np
+import pytest
+
+from conftest import cloud, golden, load_pkg, rot_angle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    m = load_pkg()
+    m.load_library()          # fails loudly if the HIP extension is missing
+    return m
+
+
+@pytest.fixture(scope="module")
+def reg10(pkg, bunny_model, bunny_data10):
+    r = pkg.Registration(bunny_model, bunny_data10, 1e-3, trans_batch=1, wide_children=0)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def rho10(oracle_mod, bunny_data10):
+    return oracle_mod.rot_radii(bunny_data10)[1]
+
+
+# ----------------------------------------------------------------------------------------------
+# distance transform
+# ----------------------------------------------------------------------------------------------
+def test_dt_geometry_matches_reference(reg10):
+    g = golden("dt_lookup")
+    V, scale, origin = reg10.dt_info()
+    assert V == 300 and scale == g["scale"]                         # bit-exact doubles (jly_3ddt.cpp:891-923)
+    assert origin == (g["xmin"], g["ymin"], g["zmin"])
+
+
+def test_dt_grid_bit_exact_vs_oracle(reg10, oracle_dt_bunny):
+    """GPU exact-EDT build vs the oracle's (Meijster, CPU): integer squared distances -> bit-identical floats."""
+    assert np.array_equal(reg10.dt_download(), oracle_dt_bunny.grid())
+
+
+def test_dt_grid_vs_reference_voxels(reg10):
+    g = golden("dt_lookup")
+    v = np.array(g["voxel"]).reshape(-1, 3)
+    ref = np.array(g["voxel_distance"], dtype=np.float32)
+    mine = reg10.dt_download()[v[:, 2], v[:, 1], v[:, 0]]
+    vox = 1.0 / g["scale"]
+    assert np.all(mine <= ref + 1e-7) and np.max(ref - mine) <= 0.35 * vox
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_dt_layouts_agree(pkg, bunny_model, bunny_data10, oracle_mod, layout):
+    r = pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_layout=layout, dt_size=96)
+    dt = oracle_mod.DistanceTransform(bunny_model, 96, 2.0)
+    assert np.array_equal(r.dt_download(), dt.grid())
+    r.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# (a) cube bounds
+# ----------------------------------------------------------------------------------------------
+def _cubes(rng, n):
+    lev = rng.integers(0, 7, n)
+    w = (1.0 / (1 << lev)).astype(np.float32)
+    c = (rng.uniform(-0.5, 0.5, (n, 3)) * (1 - w[:, None])).astype(np.float32)
+    return np.concatenate([c, w[:, None]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("layout,morton", [(1, 1), (0, 1), (1, 0)])
+def test_eval_bounds_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bunny_data10, rho10, layout, morton):
+    """ub/lb of 3 rotations x 64 cubes x {no radius, level 3..7}: rel 1e-4 (summation order only;
+    every per-point term is bit-identical)."""
+    reg = pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_layout=layout, morton_sort=morton)
+    rng = np.random.default_rng(7)
+    for v in ([1.5707963, -1.5707963, 1.5707963], [0.3, -0.2, 0.9], [-2.1, 0.4, 1.1]):
+        R = pkg.fgoicp.rodrigues(v)
+        assert np.array_equal(R, oracle_mod.rodrigues(v))
+        prot = oracle_mod.rotate(R, bunny_data10)
+        cubes = _cubes(rng, 64)
+        for level in (-1, 3, 5, 7):
+            ub, lb = reg.eval_bounds(R, cubes, level)
+            rho = rho10[level] if level >= 0 else None
+            for i, c in enumerate(cubes):
+                oub, olb = oracle_mod.cube_bound(oracle_dt_bunny, prot, rho, c[:3], c[3])
+                assert abs(ub[i] - oub) <= 1e-4 * max(oub, 1e-3)
+                assert abs(lb[i] - olb) <= 1e-4 * max(olb, 1e-3)
+                assert lb[i] <= ub[i]
+    reg.close()
+
+
+def test_eval_bounds_far_outside_grid(reg10, oracle_mod, oracle_dt_bunny, bunny_data10):
+    """Translations that push the whole cloud out of the DT grid exercise the clamp+overshoot
+    extension of DT3D::Distance (jly_3ddt.cpp:991-1025)."""
+    R = np.eye(3, dtype=np.float32)
+    cubes = np.array([[3.0, 0, 0, 0.5], [-4.0, 2.5, 0.1, 0.25], [0.2, -9.0, 7.0, 1.0], [1.2, 1.2, -1.2, 0.5]], np.float32)
+    ub, lb = reg10.eval_bounds(R, cubes, -1)
+    for i, c in enumerate(cubes):
+        oub, olb = oracle_mod.cube_bound(oracle_dt_bunny, bunny_data10, None, c[:3], c[3])
+        assert abs(ub[i] - oub) <= 1e-4 * oub and abs(lb[i] - olb) <= 1e-4 * max(olb, 1e-3)
+
+
+def test_eval_bounds_ragged_and_empty(reg10):
+    R = np.eye(3, dtype=np.float32)
+    ub, lb = reg10.eval_bounds(R, np.zeros((0, 4), np.float32), -1)
+    assert ub.size == 0 and lb.size == 0
+    rng = np.random.default_rng(3)
+    cubes = _cubes(rng, 77)                                   # not a multiple of the 8-cube group
+    ub_all, lb_all = reg10.eval_bounds(R, cubes, 4)
+    for n in (1, 7, 8, 9, 63):
+        ub, lb = reg10.eval_bounds(R, cubes[:n], 4)
+        assert np.array_equal(ub, ub_all[:n]) and np.array_equal(lb, lb_all[:n])   # batch-size independent, bitwise
+
+
+def test_eval_bounds_batch_mixed_rotations(pkg, reg10):
+    """Generic batches (cubes of different rotations inside one 8-group) take the non-uniform path."""
+    rng = np.random.default_rng(5)
+    rots = np.stack([pkg.fgoicp.rodrigues(rng.uniform(-1.5, 1.5, 3)) for _ in range(5)])
+    cubes = _cubes(rng, 37)
+    rot_of = rng.integers(0, 5, 37)
+    delta = np.array([reg10._lib.goicp_trans_delta(float(w)) for w in cubes[:, 3]], np.float32)
+    coeff = reg10.rot_coeff(5)
+    recs = [(c[0], c[1], c[2], delta[i], coeff, int(rot_of[i])) for i, c in enumerate(cubes)]
+    ub, lb = reg10.eval_bounds_batch(rots, recs)
+    for k in range(5):
+        sel = np.nonzero(rot_of == k)[0]
+        u2, l2 = reg10.eval_bounds(rots[k], cubes[sel], 5)
+        assert np.allclose(ub[sel], u2, rtol=2e-6, atol=0) and np.allclose(lb[sel], l2, rtol=2e-6, atol=1e-9)
+
+
+def test_golden_single_expansions(pkg, reg10):
+    """The reference's own InnerBnB, one expansion: min ub over the 8 children and the arg-min child
+    (tests/golden/inner_bnb.json 'single').  rel 1e-4."""
+    g = golden("inner_bnb")
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for s in case["single"]:
+            px, py, pz, pw = map(np.float32, s["parent"])
+            w = pw / np.float32(2)
+            kids = []
+            for j in range(8):
+                cx = px + np.float32(j & 1) * w; cy = py + np.float32(j >> 1 & 1) * w; cz = pz + np.float32(j >> 2 & 1) * w
+                kids.append([cx + w / np.float32(2), cy + w / np.float32(2), cz + w / np.float32(2), w, cx, cy, cz])
+            kids = np.array(kids, np.float32)
+            ub, _ = reg10.eval_bounds(R, kids[:, :4], s["level"])
+            j = int(np.argmin(ub))
+            assert abs(ub[j] - s["min_ub"]) <= 1e-4 * max(s["min_ub"], 1e-3)
+            if np.sum(np.abs(ub - ub[j]) <= 2e-5 * max(ub[j], 1e-3)) == 1:   # unambiguous arg-min
+                assert np.array_equal(kids[j, 4:7], np.array(s["best"][:3], np.float32))
+
+
+def test_golden_inner_bnb_full(pkg, reg10):
+    """Whole InnerBnB calls in the reference visit order (trans_batch=1): value rel 1e-3, node pops
+    within 1 %, best node identical."""
+    g = golden("inner_bnb")
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for s in case["full"]:
+            v, best, cnt = reg10.inner_bnb(R, s["level"], s["incumbent"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(cnt.trans_pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+            if s["value"] < s["incumbent"]:
+                assert best is not None
+                if s["level"] < 0:
+                    assert np.array_equal(best, np.array(s["best"], np.float32))
+            else:
+                assert best is None
+
+
+def test_inner_bnb_batched_same_optimum(pkg, bunny_model, bunny_data10):
+    """Expanding 16 nodes per launch visits more nodes but must return the same optimum (within
+    SSEThresh, by construction of the stop rule)."""
+    g = golden("inner_bnb")
+    reg = pkg.Registration(bunny_model, bunny_data10, 1e-3, trans_batch=16)
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for s in case["full"]:
+            v, _, _ = reg.inner_bnb(R, s["level"], s["incumbent"])
+            assert abs(v - s["value"]) <= g["sse_threshold"] + 1e-3 * s["value"]
+    reg.close()
+
+
+def test_eval_sse_golden(reg10):
+    g = golden("icp_dt_score")
+    sse = reg10.compute_sse_error(np.array(g["R"]), np.array(g["t"]))
+    assert abs(sse - g["dt_sse"]) <= 1e-4 * g["dt_sse"]               # jly_goicp.cpp:93-132
+
+
+# ----------------------------------------------------------------------------------------------
+# (b) ICP
+# ----------------------------------------------------------------------------------------------
+def test_nn_exact_vs_reference_kdtree(reg10):
+    g = golden("nn")
+    q = np.array(g["query"], np.float32).reshape(-1, 3)
+    idx, d2 = reg10.nn_query(q)
+    assert np.array_equal(d2, np.array(g["dist_sq"], np.float32))      # bit-exact squared distances
+    assert np.mean(idx == np.array(g["index"])) > 0.999                # ties only
+
+
+def test_nn_vs_bruteforce(reg10, oracle_mod, bunny_model):
+    rng = np.random.default_rng(11)
+    q = rng.uniform(-1.5, 1.5, (2000, 3)).astype(np.float32)
+    q[:500] = bunny_model[rng.integers(0, len(bunny_model), 500)]      # exact hits: distance 0, lowest index wins
+    idx, d2 = reg10.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(bunny_model, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+
+
+def test_icp_run_golden(pkg, reg10):
+    """IterativeClosestPoint3D::run / ICP3D::Run with forced iteration counts: 1e-4 abs on R,t for
+    <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3."""
+    g = golden("icp_iter")
+    for c in g["cases"]:
+        icp = pkg.IterativeClosestPoint3D(reg10, c["max_iter"], c["err_diff"], c["R0"], c["t0"])
+        err, R, t = icp.run()
+        tol = 1e-4 if c["max_iter"] <= 10 else 1e-3
+        assert np.abs(R.ravel() - np.array(c["R"])).max() <= tol
+        assert np.abs(t - np.array(c["t"])).max() <= tol
+        assert abs(err - c["err"]) <= 1e-3 * c["err"]
+        if c["max_iter"] <= 10:
+            assert icp.iters == c["max_iter"]
+
+
+def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):
+    reg = pkg.Registration(bunny_model, bunny_data10, 1e-3)
+    errs = [reg.icp_step().best_sse for _ in range(6)]
+    assert all(b <= a * (1 + 1e-5) for a, b in zip(errs, errs[1:]))
+    g = golden("icp_iter")["cases"][0]                                 # first pass error from identity
+    assert abs(errs[0] - g["err"]) <= 1e-3 * g["err"]
+    reg.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# end to end (FastGoICP::run == GoICP::Register)
+# ----------------------------------------------------------------------------------------------
+def _e2e(pkg, tag, model, data, **params):
+    g = golden("e2e_" + tag)
+    eng = pkg.FastGoICP(model, data, g["mse_threshold"], **params)
+    eng.run()
+    assert eng.finished
+    sse = eng.get_best_error()
+    assert rot_angle(eng.optR, np.array(g["R"])) <= 2e-3               # rad
+    assert np.linalg.norm(eng.optT - np.array(g["t"])) <= 2e-3
+    assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+    assert sse < g["sse_threshold"]
+    return eng, g
+
+
+def test_e2e_rand100_reference_order(pkg):
+    eng, g = _e2e(pkg, "rand100", cloud("model_rand"), cloud("data_rand"), trans_batch=1, wide_children=0)
+    c = eng.counters
+    assert c.rot_pops == g["rNodeCount"]
+    assert abs(c.trans_pops - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]
+
+
+def test_e2e_rand100_wide(pkg):
+    _e2e(pkg, "rand100", cloud("model_rand"), cloud("data_rand"))
+
+
+def test_e2e_bunny10_reference_order(pkg, bunny_model, bunny_data10):
+    eng, g = _e2e(pkg, "bunny10", bunny_model, bunny_data10, trans_batch=1, wide_children=0)
+    c = eng.counters
+    assert abs(c.rot_pops - g["rNodeCount"]) <= 0.02 * g["rNodeCount"]
+    assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"]
+
+
+def test_e2e_bunny10_wide(pkg, bunny_model, bunny_data10):
+    _e2e(pkg, "bunny10", bunny_model, bunny_data10)
+
+
+def test_e2e_bunny_full_wide(pkg, bunny_model, bunny_data, tmp_path):
+    """BASELINE configs[1]: bunny_goicp, N = 30379, V = 300 (reference CPU: 502.7 s)."""
+    eng, g = _e2e(pkg, "bunny_full", bunny_model, bunny_data)
+    out = tmp_path / "output.toml"
+    eng.write_output(out)
+    txt = out.read_text()
+    assert "rotation" in txt and "translation" in txt and "sse" in txt
+
+
+def test_sharded_two_ranks_same_optimum(pkg, bunny_model, bunny_data10):
+    """Rotation cubes dealt to 2 ranks (both on this GPU, stepped alternately) with a min-exchange of
+    the best error between steps reach the single-rank optimum (SURVEY 8e invariant)."""
+    from cuda_go_icp_amd import sharded
+    g = golden("e2e_bunny10")
+    engines = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"]) for _ in range(2)]
+    sse, R, t, stats = sharded.run_local_ranks(engines, rot_pops_per_step=4)
+    assert rot_angle(R, np.array(g["R"])) <= 2e-3 and np.linalg.norm(t - np.array(g["t"])) <= 2e-3
+    assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+
+
+# ----------------------------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE sizes; the oracle would take minutes here)
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def s1(pkg):
+    from cuda_go_icp_amd import synth
+    return synth.make_pair(**{k: synth.S1[k] for k in ("seed", "M", "N")})
+
+
+def test_fullsize_additivity_and_monotonicity(pkg, s1):
+    """N = 40 000, V = 300: (i) bounds are sums over points -> evaluating the cloud concatenated with
+    itself doubles them; (ii) lb <= ub; (iii) at a fixed centre lb grows as the cube shrinks and the
+    radius level deepens; (iv) Morton order is only a permutation."""
+    target, source, _, _ = s1
+    rng = np.random.default_rng(1)
+    cubes = _cubes(rng, 256)
+    R = pkg.fgoicp.rodrigues([0.4, -0.3, 0.8])
+    a = pkg.Registration(target, source, 1e-3)
+    b = pkg.Registration(target, np.concatenate([source, source]), 1e-3)
+    c = pkg.Registration(target, source, 1e-3, morton_sort=0)
+    for level in (-1, 4):
+        ua, la = a.eval_bounds(R, cubes, level)
+        ub2, lb2 = b.eval_bounds(R, cubes, level)
+        uc, lc = c.eval_bounds(R, cubes, level)
+        assert np.allclose(ub2, 2 * ua, rtol=1e-5) and np.allclose(lb2, 2 * la, rtol=1e-5, atol=1e-6)
+        assert np.allclose(uc, ua, rtol=1e-5) and np.allclose(lc, la, rtol=1e-5, atol=1e-6)
+        assert np.all(la <= ua)
+    centre = np.tile(np.array([[0.1, -0.05, 0.2]], np.float32), (6, 1))
+    ws = np.array([[1.0], [0.5], [0.25], [0.125], [0.0625], [0.03125]], np.float32)
+    _, lbs = a.eval_bounds(R, np.concatenate([centre, ws], 1), -1)
+    assert np.all(np.diff(lbs) >= 0)
+    ubs = [a.eval_bounds(R, np.concatenate([centre[:1], ws[3:4]], 1), lv)[0][0] for lv in (2, 4, 6, 8, -1)]
+    assert all(x <= y * (1 + 1e-6) for x, y in zip(ubs, ubs[1:]))
+    for r in (a, b, c):
+        r.close()
+
+
+def test_fullsize_registration_recovers_ground_truth(pkg, s1):
+    """S1 (N = M = 40 000): the known rigid motion is recovered; noise sigma 0.002 -> MSE ~ 1.2e-5."""
+    target, source, Rgt, tgt = s1
+    eng = pkg.FastGoICP(target, source, 1e-3)
+    eng.run()
+    assert rot_angle(eng.optR, Rgt) <= 5e-3 and np.linalg.norm(eng.optT - tgt) <= 5e-3
+    assert eng.get_best_error() < eng.sse_threshold
+
+
+def test_fullsize_nn_idempotent(pkg, s1):
+    target, source, _, _ = s1
+    reg = pkg.Registration(target, source[:64], 1e-3)
+    idx, d2 = reg.nn_query(target)                       # every target point is its own nearest neighbour
+    assert np.all(d2 == 0)
+    assert np.all(np.all(target[idx] == target, axis=1))
+    reg.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# error behaviour of the boundary
+# ----------------------------------------------------------------------------------------------
+def test_invalid_arguments(pkg, bunny_model, bunny_data10):
+    with pytest.raises(pkg.GoicpError):
+        pkg.Registration(np.zeros((0, 3), np.float32), bunny_data10)
+    with pytest.raises(pkg.GoicpError):
+        pkg.Registration(bunny_model, bunny_data10, dt_size=4)
+    reg = pkg.Registration(bunny_model[:5], bunny_data10[:1], 1e-3, dt_size=32)     # tiny clouds are legal
+    ub, lb = reg.eval_bounds(np.eye(3), np.array([[0, 0, 0, 0.5]], np.float32), -1)
+    assert np.isfinite(ub[0]) and lb[0] <= ub[0]
+    idx, d2 = reg.nn_query(bunny_model[:5])
+    assert np.array_equal(idx, np.arange(5)) and np.all(d2 == 0)
+    reg.close()

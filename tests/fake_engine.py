@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE: a stand-in for fgoicp.FastGoICP's stepped interface whose bounds come from
+the CPU oracle, so that the sharding / exchange / termination protocol of
+cuda-go-icp_amd/sharded.py can be exercised without a GPU (gloo, world_size 2).  Never shipped,
+never used by the product."""
+import heapq
+import math
+
+import numpy as np
+
+import oracle as O
+
+PI, SQRT3 = 3.1415926536, 1.732050808
+
+
+class FakeEngine:
+    def __init__(self, model, data, mse):
+        self.model, self.data = model, data
+        self.dt = O.DistanceTransform(model, 64, 2.0)      # coarse grid: these tests are about the protocol
+        self.kd = O.KdTree(model)
+        self.rho = O.rot_radii(data)[1]
+        self.sse_threshold = np.float32(mse) * np.float32(len(data))
+        self.err_diff = np.float32(mse) / np.float32(10000)
+        self.rank, self.world = 0, 1
+        self.cubes = 0
+
+    def set_shard(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def _icp(self, R, t):
+        _, R, t, _ = self.kd.icp_run(self.data, R, t, 10000, self.err_diff)
+        return O.dt_sse(self.dt, self.data, R, t), R, t
+
+    def register_begin(self):
+        I, Z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+        self.best, self.R, self.t = O.dt_sse(self.dt, self.data, I, Z), I, Z
+        e, R, t = self._icp(I, Z)
+        if e < self.best:
+            self.best, self.R, self.t = e, R, t
+        self.q, self.tie, self.early, self.conv, self.pops = [], 0, False, False, 0
+        root = (np.float32(-PI), np.float32(-PI), np.float32(-PI), np.float32(2 * PI), 0)
+        if self.world == 1:
+            self._push(0.0, root)
+        else:
+            k = 0
+            for a in range(8):
+                c1 = self._child(root, a)
+                for b in range(8):
+                    if k % self.world == self.rank:
+                        self._push(0.0, self._child(c1, b))
+                    k += 1
+
+    @staticmethod
+    def _child(n, j):
+        w = n[3] / np.float32(2)
+        return (n[0] + np.float32(j & 1) * w, n[1] + np.float32(j >> 1 & 1) * w, n[2] + np.float32(j >> 2 & 1) * w, w, n[4] + 1)
+
+    def _push(self, lb, node):
+        self.tie += 1
+        heapq.heappush(self.q, (float(lb), -float(node[3]), self.tie, node))
+
+    def register_step(self, max_pops):
+        pops = 0
+        while not (self.early or self.conv) and self.q and pops < max_pops:
+            lb, _, _, parent = heapq.heappop(self.q)
+            self.pops += 1
+            pops += 1
+            if self.best - lb <= self.sse_threshold:
+                self.conv = True
+                break
+            for j in range(8):
+                c = self._child(parent, j)
+                v = np.array([c[0] + c[3] / 2, c[1] + c[3] / 2, c[2] + c[3] / 2], np.float32)
+                if math.sqrt(float(v @ v)) - SQRT3 * float(c[3]) / 2 > PI:
+                    continue
+                R = O.rodrigues(v)
+                prot = O.rotate(R, self.data)
+                ub, node, _, cubes = O.inner_bnb(self.dt, prot, None, self.best, self.sse_threshold)
+                self.cubes += cubes
+                if ub < self.best:
+                    t = node[:3] + node[3] / np.float32(2)
+                    self.best, self.R, self.t = ub, R, t
+                    e, Ri, ti = self._icp(R, t)
+                    if e < self.best:
+                        self.best, self.R, self.t = e, Ri, ti
+                    if self.best < self.sse_threshold:
+                        self.early = True
+                        break
+                    self.q = [x for x in self.q if x[0] < self.best]
+                    heapq.heapify(self.q)
+                lbv, _, _, cubes = O.inner_bnb(self.dt, prot, self.rho[min(c[4], 19)], self.best, self.sse_threshold)
+                self.cubes += cubes
+                if lbv < self.best:
+                    self._push(lbv, c)
+        fin = self.early or self.conv or not self.q
+        return {"finished": fin, "early_exit": self.early, "best_sse": float(self.best),
+                "frontier_lb": float(self.q[0][0]) if (self.q and not fin) else math.inf, "rot_pops": self.pops}
+
+    def pose(self):
+        return float(self.best), np.asarray(self.R, np.float32).reshape(9), np.asarray(self.t, np.float32)
+
+    def offer_best(self, sse, R, t):
+        if sse < self.best:
+            self.best, self.R, self.t = np.float32(sse), np.asarray(R, np.float32).reshape(3, 3), np.asarray(t, np.float32)
+            self.q = [x for x in self.q if x[0] < self.best]
+            heapq.heapify(self.q)
+            if self.best < self.sse_threshold:
+                self.early = True
+
+    def register_end(self):
+        pass

@@ -1,0 +1,171 @@
+"""CPU-side tests of the boundary: the C-ABI library loads and exports every symbol
+include/goicp_mi355.h declares, config / cloud loading mirror the reference's behaviour, and the
+product fails loudly (no CPU fallback) when no GPU is present.  No compute calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_pkg
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    ge.build()
+    return load_pkg()
+
+
+def test_header_symbols_all_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "goicp_mi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(goicp_[a-z0-9_]+)\s*\(", hdr))
+    from cuda_go_icp_amd import binding
+    lib = pkg.load_library()
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "symbol %s declared in the header but not exported" % name
+    assert declared == set(binding.SYMBOLS), (declared ^ set(binding.SYMBOLS))
+    assert lib.goicp_abi_version() == 1
+
+
+def test_struct_sizes_match_abi(pkg):
+    from cuda_go_icp_amd import binding as B
+    import ctypes as C
+    assert C.sizeof(B.CCube) == 24
+    assert C.sizeof(B.CCounters) == 56
+    assert C.sizeof(B.CStepStatus) == 24
+    assert C.sizeof(B.CResult) == 4 * (9 + 3 + 9 + 3 + 1 + 1) + 56 + 16
+
+
+CFG = """# comment
+[info]
+description = "Register data # not a comment"   # trailing comment
+
+[io]
+target = "../data/bunny/model_bunny.txt"
+source = '../data/bunny/data_bunny.txt'
+output = "output.toml"
+
+[params]
+mode = 4
+trim = true
+subsample = 1.7          # clamped to 1
+mse_threshold = 1e-12    # clamped to 1e-10
+resize = 0.01
+authors = ["a",
+           "b"]
+
+[params.rotation]
+xmin = -90
+search_depth = 7
+
+[visualization]
+theta = 0.5
+spin_after_finish = true
+"""
+
+
+def test_config_parse_defaults_and_clamps(pkg, tmp_path):
+    p = tmp_path / "c.toml"
+    p.write_text(CFG)
+    c = pkg.Config(p)
+    assert c.mode == 4 and c.trim is True
+    assert c.subsample == 1.0                                   # src/common.cpp:63
+    assert c.mse_threshold == pytest.approx(1e-10)               # src/common.cpp:64
+    assert c.resize == pytest.approx(0.01)
+    assert c.io.target.endswith("model_bunny.txt") and c.io.source.endswith("data_bunny.txt")
+    assert c.io.output == "output.toml" and c.io.visualization == ""
+    assert c.viz.theta == 0.5 and c.viz.phi == pytest.approx(0.4) and c.viz.spin_after_finish
+    assert c.rotation.xmin == -90 and c.rotation.xmax == 180 and c.rotation.search_depth == 7
+    assert c.description == "Register data # not a comment"
+
+
+def test_config_errors(pkg, tmp_path):
+    with pytest.raises(pkg.GoicpError) as e:
+        pkg.Config(tmp_path / "missing.toml")
+    assert e.value.code == -3
+    p = tmp_path / "bad.toml"
+    p.write_text("[info]\ndescription = \"x\"\n[params\nmode = 1\n")
+    with pytest.raises(pkg.GoicpError):
+        pkg.Config(p)
+    p.write_text("[params]\nmode = 1\n")                       # reference: bad_optional_access on info.description
+    with pytest.raises(pkg.GoicpError):
+        pkg.Config(p)
+    p.write_text("[info]\ndescription = \"d\"\n")              # no [params]: defaults
+    c = pkg.Config(p)
+    assert c.mode == 1 and c.subsample == 1.0 and c.mse_threshold == pytest.approx(1e-5) and c.resize == 1.0
+
+
+def _write_ply(path, pts, binary, crlf=False, extra=False):
+    nl = "\r\n" if crlf else "\n"
+    hdr = ["ply", "format %s 1.0" % ("binary_little_endian" if binary else "ascii"), "comment test",
+           "element vertex %d" % len(pts), "property float x", "property float y", "property float z"]
+    if extra:
+        hdr += ["property uchar red", "property uchar green", "property uchar blue"]
+    hdr += ["element face 1", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as f:
+        f.write((nl.join(hdr) + nl).encode())
+        for p in pts:
+            if binary:
+                f.write(np.asarray(p, "<f4").tobytes() + (bytes([1, 2, 3]) if extra else b""))
+            else:
+                f.write((" ".join("%.9g" % v for v in p) + (" 1 2 3" if extra else "") + "\n").encode())
+        f.write(bytes([3]) + np.array([0, 1, 2], "<i4").tobytes() if binary else b"3 0 1 2\n")
+
+
+@pytest.mark.parametrize("binary,crlf,extra", [(False, False, False), (True, True, True), (True, False, False), (False, True, True)])
+def test_load_cloud_ply(pkg, tmp_path, binary, crlf, extra):
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(257, 3)).astype(np.float32)
+    p = tmp_path / "c.PLY"                                        # extension match is case-insensitive
+    _write_ply(p, pts, binary, crlf, extra)
+    out = pkg.load_cloud(p, 1.0, 2.0)
+    assert out.shape == (257, 3) and np.array_equal(out, np.float32(2.0) * pts)
+
+
+def test_load_cloud_txt_and_subsample(pkg, tmp_path):
+    pts = np.fromfile(os.path.join(GOLDEN, "data_rand.f32"), dtype="<f4").reshape(-1, 3)
+    p = tmp_path / "c.txt"
+    with open(p, "w") as f:
+        f.write("%d\n" % len(pts))
+        for q in pts:
+            f.write("%.9g %.9g %.9g\n" % tuple(q))
+    assert np.array_equal(pkg.load_cloud(p, 1.0, 1.0), pts)
+    a = pkg.load_cloud(p, 0.5, 1.0, seed=42)
+    b = pkg.load_cloud(p, 0.5, 1.0, seed=42)
+    assert np.array_equal(a, b) and 0 < len(a) <= 50              # capped at floor(N*s) (src/common.cpp:167)
+    assert len(pkg.load_cloud(p, 0.0, 1.0, seed=1)) == 0
+
+
+def test_load_cloud_errors(pkg, tmp_path):
+    for name in ("nope.ply", "nope.txt", "noext", "cloud.xyz"):
+        with pytest.raises(pkg.GoicpError) as e:
+            pkg.load_cloud(tmp_path / name)
+        assert e.value.code == -2
+    p = tmp_path / "short.txt"
+    p.write_text("5\n0 0 0\n1 1 1\n")
+    with pytest.raises(pkg.GoicpError):
+        pkg.load_cloud(p)
+    p = tmp_path / "noxyz.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float a\nend_header\n0\n")
+    with pytest.raises(pkg.GoicpError):
+        pkg.load_cloud(p)
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pts = np.random.default_rng(0).normal(size=(50, 3)).astype(np.float32)
+    with pytest.raises(pkg.GoicpError) as e:
+        pkg.Registration(pts, pts)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_rodrigues_host_helper_matches_oracle(pkg, oracle_mod):
+    rng = np.random.default_rng(1)
+    for v in rng.uniform(-3, 3, (50, 3)):
+        assert np.array_equal(pkg.fgoicp.rodrigues(v), oracle_mod.rodrigues(v))
+    assert np.array_equal(pkg.fgoicp.rodrigues([0, 0, 0]), np.eye(3, dtype=np.float32))

@@ -1,5 +1,5 @@
 """Deterministic synthetic clouds for the configurations whose data cannot travel to the GPU box
-(SURVEY.md 8d): a closed, non-symmetric star-shaped surface r(theta,phi) = 0.6 + 0.15*sum a_k Y_k,
+(SURVEY.md 8d): a closed, non-symmetric star-shaped surface r(theta,phi) = 0.6 + 0.35*tanh(sum a_k Y_k),
 bounded in [-1,1]^3 like the reference's normalised scans.
 
   S1 "bunny-scale":  seed 20241223, M = N = 40 000, V = 300
@@ -24,19 +24,21 @@ def _rodrigues(v):
 
 
 def _surface(rng, n, coef):
-    # uniform directions; radius from a few low-order real harmonics (not area-uniform, irrelevant here)
+    # uniform directions; radius from low-order harmonics with odd terms (x, y, z, xyz) so that the
+    # shape has no rotational or point symmetry (a near-sphere would make Go-ICP's early exit
+    # accept any rotation).  Radius stays in [0.25, 0.95].  Not area-uniform; irrelevant here.
     d = rng.normal(size=(n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     x, y, z = d.T
-    basis = np.stack([x, y, z, x * y, y * z, 3 * z * z - 1], axis=1)
-    r = 0.6 + 0.15 * basis @ coef / 2.0
+    basis = np.stack([x, y, z, x * y, y * z, 3 * z * z - 1, x * x - y * y, 5 * x * y * z], axis=1)
+    r = 0.6 + 0.35 * np.tanh(basis @ coef)
     return d * r[:, None]
 
 
 def make_pair(seed=S1["seed"], M=S1["M"], N=S1["N"], noise=0.002, V=None):
     """-> (target (M,3) f32, source (N,3) f32, R_gt (3,3), t_gt (3,)) with target ~= R_gt*source + t_gt."""
     rng = np.random.default_rng(seed)
-    coef = rng.uniform(-1, 1, size=6)
+    coef = rng.uniform(-1, 1, size=8)
     target = _surface(rng, M, coef)
     moved = _surface(rng, N, coef) + rng.normal(scale=noise, size=(N, 3))
     R = _rodrigues(GT_AXIS_ANGLE)

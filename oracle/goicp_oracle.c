@@ -339,6 +339,16 @@ void orc_cube_bound_omp(const orc_dt* dt, const float* p, int N, const float* rh
 	*lb_out = lb;
 }
 
+void orc_cube_bounds_batch(const orc_dt* dt, const float* p, int N, const float* rho, const float* cubes4, int B,
+                           float* ub, float* lb, int parallel)
+{
+	/* the same per-cube arithmetic and sum order as orc_cube_bound; cubes are independent, so the
+	 * all-core CPU baseline parallelises over cubes */
+#pragma omp parallel for schedule(dynamic, 4) if (parallel)
+	for (int b = 0; b < B; b++)
+		orc_cube_bound(dt, p, N, rho, cubes4[4 * b], cubes4[4 * b + 1], cubes4[4 * b + 2], cubes4[4 * b + 3], &ub[b], &lb[b]);
+}
+
 float orc_dt_sse(const orc_dt* dt, const float* d, int N, const float R[9], const float t[3])
 {
 	/* jly_goicp.cpp:100-129 */

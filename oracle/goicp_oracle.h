@@ -59,6 +59,9 @@ void  orc_cube_bound(const orc_dt* dt, const float* prot_xyz, int N, const float
 /* same arithmetic per point, OpenMP over points (sum order differs); for the all-core CPU baseline */
 void  orc_cube_bound_omp(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null,
                          float tx, float ty, float tz, float w_child, float* ub, float* lb);
+/* B cubes {cx,cy,cz,w_child}; parallel != 0: OpenMP over cubes (identical results) */
+void  orc_cube_bounds_batch(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null,
+                            const float* cubes4, int B, float* ub, float* lb, int parallel);
 /* sum_i Distance(R p_i + t)^2 (jly_goicp.cpp:100-129 with trimFraction 0) */
 float orc_dt_sse(const orc_dt* dt, const float* data_xyz, int N, const float R[9], const float t[3]);
 

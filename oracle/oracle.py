@@ -53,6 +53,7 @@ def lib():
         L.orc_rotate.argtypes = [fp, fp, C.c_int, fp]
         L.orc_cube_bound.argtypes = [dp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp]
         L.orc_cube_bound_omp.argtypes = L.orc_cube_bound.argtypes
+        L.orc_cube_bounds_batch.argtypes = [dp, fp, C.c_int, fp, fp, C.c_int, fp, fp, C.c_int]
         L.orc_dt_sse.argtypes = [dp, fp, C.c_int, fp, fp]
         L.orc_dt_sse.restype = C.c_float
         L.orc_inner_bnb.argtypes = [dp, fp, C.c_int, fp, C.c_float, C.c_float, fp, fp,
@@ -173,6 +174,18 @@ def cube_bound(dt, prot, rho, t, w_child, omp=False):
     fn(C.byref(dt.dt), pp, len(p), rp, np.float32(t[0]), np.float32(t[1]), np.float32(t[2]), np.float32(w_child),
        C.byref(ub), C.byref(lb))
     return np.float32(ub.value), np.float32(lb.value)
+
+
+def cube_bounds_batch(dt, prot, rho, cubes4, parallel=False):
+    p, pp = _f(prot)
+    rp = None
+    if rho is not None:
+        rho, rp = _f(rho)
+    c, cp = _f(np.asarray(cubes4).reshape(-1, 4))
+    ub, lb = np.empty(len(c), np.float32), np.empty(len(c), np.float32)
+    lib().orc_cube_bounds_batch(C.byref(dt.dt), pp, len(p), rp, cp, len(c), ub.ctypes.data_as(C.POINTER(C.c_float)),
+                                lb.ctypes.data_as(C.POINTER(C.c_float)), 1 if parallel else 0)
+    return ub, lb
 
 
 def dt_sse(dt, data, R, t):

@@ -331,9 +331,10 @@ def test_fullsize_additivity_and_monotonicity(pkg, s1):
 
 
 def test_fullsize_registration_recovers_ground_truth(pkg, s1):
-    """S1 (N = M = 40 000): the known rigid motion is recovered; noise sigma 0.002 -> MSE ~ 1.2e-5."""
+    """S1 (N = M = 40 000): the known rigid motion is recovered (noise sigma 0.002 + DT quantisation
+    -> SSE ~ 1-2, below SSEThresh = 4)."""
     target, source, Rgt, tgt = s1
-    eng = pkg.FastGoICP(target, source, 1e-3)
+    eng = pkg.FastGoICP(target, source, 1e-4)     # SSEThresh = 4.0: only the true basin gets below it
     eng.run()
     assert rot_angle(eng.optR, Rgt) <= 5e-3 and np.linalg.norm(eng.optT - tgt) <= 5e-3
     assert eng.get_best_error() < eng.sse_threshold

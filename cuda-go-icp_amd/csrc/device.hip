@@ -216,106 +216,303 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 }
 
 // ------------------------------------------------------------------------------------------------
-// (b) ICP: exact 1-NN in the implicit k-d tree, stackless (the parent is re-read on the way up:
-// no per-thread stack, no scratch, no LDS -> ~40 VGPRs, full occupancy for a latency-bound walk)
+// (b) ICP: exact 1-NN in the flattened k-d tree.
+// The walk is a chain of dependent accesses, so latency per step and the NUMBER of steps decide
+// the speed, not bandwidth.  Measured on MI355X: a plain split-plane walk costs ~1000 leaf rounds
+// per wavefront for queries far from the surface (3.9 ms per pass at the identity pose).  Hence:
+//  (1) every node carries the tight bounding boxes of its two children (16-bit, conservatively
+//      quantised, 24 B/node): a subtree is entered only if its box is within the best distance;
+//  (2) the search starts from the upper bound (DT(q) + 2.5 voxel)^2 read from the distance
+//      transform the engine already holds, so even far queries go straight to the few leaves
+//      around their true neighbour;
+//  (3) the box records (<= 96 KB) are staged in LDS once per workgroup: a step costs LDS latency;
+//  (4) a leaf is two aligned 128-B lines of 16 float4 slots (padded with +inf), fetched with
+//      independent loads: one memory latency per leaf, no offset indirection;
+//  (5) the walk is stackless (heap indices; on the way up the parent's record is re-read from LDS
+//      and the visit order re-derived from the box distances, which depend on the query only) and
+//      re-converges the wavefront before every leaf scan, so a wave pays max-over-lanes (not
+//      sum-over-lanes) memory latencies.
+// Exactness: box lower bounds use the same monotone float accumulation as the point distances,
+// boxes are conservative, ties go to the lowest original index -> identical to brute force.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pick(int dim, float x, float y, float z) { return dim == 0 ? x : (dim == 1 ? y : z); }
+constexpr int kLdsNodes = 4096;        // 96 KB of LDS: the whole tree up to M = 64 k target points, the top 12 levels beyond
+constexpr int kIcpThreads = 256;
 
-__device__ __forceinline__ void kd_nearest(const KdDesc& kd, float qx, float qy, float qz,
-                                           float& best, int& bidx, float& mx, float& my, float& mz)
+__device__ __forceinline__ void stage_nodes(const KdDesc& kd, uint2* lds)
+{
+	const int n = (kd.L < kLdsNodes ? kd.L : kLdsNodes) * 3;
+	for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = kd.boxes[i];
+	__syncthreads();
+}
+
+// squared distance from q to the box {lo, hi} decoded from three packed words (x: lo|hi<<16, ...)
+__device__ __forceinline__ float box_lb(const KdDesc& kd, unsigned wx, unsigned wy, unsigned wz, float qx, float qy, float qz)
+{
+	const float lox = kd.root_lo[0] + (float)(wx & 0xffffu) * kd.step[0], hix = kd.root_lo[0] + (float)(wx >> 16) * kd.step[0];
+	const float loy = kd.root_lo[1] + (float)(wy & 0xffffu) * kd.step[1], hiy = kd.root_lo[1] + (float)(wy >> 16) * kd.step[1];
+	const float loz = kd.root_lo[2] + (float)(wz & 0xffffu) * kd.step[2], hiz = kd.root_lo[2] + (float)(wz >> 16) * kd.step[2];
+	const float ex = fmaxf(fmaxf(lox - qx, qx - hix), 0.f);
+	const float ey = fmaxf(fmaxf(loy - qy, qy - hiy), 0.f);
+	const float ez = fmaxf(fmaxf(loz - qz, qz - hiz), 0.f);
+	float d = ex * ex;         // same accumulation order as the point distance below
+	d += ey * ey;
+	d += ez * ez;
+	return d;
+}
+
+template <bool kAllLds>
+__device__ __forceinline__ void kd_nearest(const KdDesc& kd, const uint2* lds, float qx, float qy, float qz, float bound,
+                                           float& best, int& bidx, int& bslot)
 {
 	const int L = kd.L;
-	best = INFINITY; bidx = INT_MAX; mx = my = mz = 0.f;
+	best = bound; bidx = INT_MAX; bslot = 0;
 	int node = 1;
-	while (true) {
-		while (node < L) {                       // descend, near side first
-			const float2 nd = kd.nodes[node];
-			float diff = pick(__float_as_int(nd.y), qx, qy, qz) - nd.x;
-			node = 2 * node + (diff < 0.f ? 0 : 1);
+	bool down = true, done = false;
+	while (__any(!done)) {
+		// ---- phase A: to the next leaf (or off the root); one branch-free step per iteration ----
+		while (!done && (!down || node < L)) {
+			const int at = down ? node : (node >> 1);
+			uint2 w0, w1, w2;
+			if (kAllLds || at < kLdsNodes) { w0 = lds[3 * at]; w1 = lds[3 * at + 1]; w2 = lds[3 * at + 2]; }
+			else { w0 = kd.boxes[3 * at]; w1 = kd.boxes[3 * at + 1]; w2 = kd.boxes[3 * at + 2]; }
+			const float lbl = box_lb(kd, w0.x, w0.y, w1.x, qx, qy, qz);      // left child 2*at
+			const float lbr = box_lb(kd, w1.y, w2.x, w2.y, qx, qy, qz);      // right child 2*at+1
+			const int first = 2 * at + (lbl <= lbr ? 0 : 1);
+			const float lb_first = fminf(lbl, lbr), lb_second = fmaxf(lbl, lbr);
+			if (down) {
+				if (lb_first <= best) node = first; else down = false;       // nothing closer below: turn around here
+			} else if (node == 1) {
+				done = true;                                                  // walked off the root
+			} else if (node == first && lb_second <= best) {
+				node = first ^ 1; down = true;                                // the sibling may hold a closer point
+			} else {
+				node = at;
+			}
 		}
-		const int leaf = node - L;
-		const int s = kd.leaf_start[leaf], e = kd.leaf_start[leaf + 1];
-		for (int k = s; k < e; k++) {
-			const float4 p = kd.pts[k];
-			// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
-			float d0 = qx - p.x, d1 = qy - p.y, d2 = qz - p.z;
-			float d = d0 * d0;
-			d += d1 * d1;
-			d += d2 * d2;
-			int id = __float_as_int(p.w);
-			if (d < best || (d == best && id < bidx)) { best = d; bidx = id; mx = p.x; my = p.y; mz = p.z; }
+		// ---- phase B: scan the leaf ----
+		if (!done) {
+			const int base = (node - L) * kLeafSlots;
+			float4 p[kLeafSlots];
+#pragma unroll
+			for (int k = 0; k < kLeafSlots; k++) p[k] = kd.pts[base + k];
+#pragma unroll
+			for (int k = 0; k < kLeafSlots; k++) {
+				// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
+				const float d0 = qx - p[k].x, d1 = qy - p[k].y, d2 = qz - p[k].z;
+				float d = d0 * d0;
+				d += d1 * d1;
+				d += d2 * d2;
+				const int id = __float_as_int(p[k].w);
+				if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bslot = base + k; }
+			}
+			down = false;
+			if (node == 1) done = true;                                       // single-leaf tree
 		}
-		bool done = false;
-		while (true) {                           // ascend until an unvisited far side may hold a closer point
-			if (node == 1) { done = true; break; }
-			const int parent = node >> 1;
-			const float2 nd = kd.nodes[parent];
-			float diff = pick(__float_as_int(nd.y), qx, qy, qz) - nd.x;
-			int nearc = 2 * parent + (diff < 0.f ? 0 : 1);
-			if (node == nearc && diff * diff <= best) { node = nearc ^ 1; break; }
-			node = parent;
-		}
-		if (done) break;
 	}
 }
 
-constexpr int kIcpThreads = 64;   // one wavefront per block: reductions stay in-register
-
-__global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(
-    const float4* __restrict__ src, int N, Pose pose, KdDesc kd, float cqx, float cqy, float cqz,
-    float cmx, float cmy, float cmz, float* __restrict__ partials)
+// upper bound on the NN distance from the distance transform: DT(q) is exact between voxel centres,
+// query and neighbour are each within sqrt(3)/2 voxel of theirs (2.5 voxels of slack, squared)
+template <int LAYOUT>
+__device__ __forceinline__ float nn_upper_bound(const DtDesc& dt, float qx, float qy, float qz)
 {
+	const float d = dt_distance<LAYOUT>(dt, qx, qy, qz) + (float)(2.5 / dt.scale);
+	return d * d;
+}
+
+template <bool kAllLds, int LAYOUT>
+__global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
+                                                               const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
+                                                               float* __restrict__ partials)
+{
+	__shared__ uint2 lds_nodes[kLdsNodes * 3];
+	__shared__ float red[kIcpThreads / 64][kIcpAcc];
+	if (st->converged) return;                                          // loop already finished: queued launches drain
+	stage_nodes(kd, lds_nodes);
+	const int i = blockIdx.x * kIcpThreads + threadIdx.x;
+	const bool valid = i < N;
+	const float4 p = src[valid ? i : N - 1];
+	// jly_icp3d.hpp:222-224, left-to-right float sums
+	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+	float d2; int id, slot;
+	kd_nearest<kAllLds>(kd, lds_nodes, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz), d2, id, slot);
 	float acc[kIcpAcc];
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
-	for (int i = blockIdx.x * kIcpThreads + threadIdx.x; i < N; i += gridDim.x * kIcpThreads) {
-		const float4 p = src[i];
-		// jly_icp3d.hpp:222-224
-		float qx = pose.R[0] * p.x + pose.R[1] * p.y + pose.R[2] * p.z + pose.t[0];
-		float qy = pose.R[3] * p.x + pose.R[4] * p.y + pose.R[5] * p.z + pose.t[1];
-		float qz = pose.R[6] * p.x + pose.R[7] * p.y + pose.R[8] * p.z + pose.t[2];
-		float d2, mx, my, mz; int id;
-		kd_nearest(kd, qx, qy, qz, d2, id, mx, my, mz);
-		float ax = qx - cqx, ay = qy - cqy, az = qz - cqz;   // pivots keep the covariance sums well conditioned
-		float bx = mx - cmx, by = my - cmy, bz = mz - cmz;
-		acc[0] += ax; acc[1] += ay; acc[2] += az;
-		acc[3] += bx; acc[4] += by; acc[5] += bz;
-		acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
-		acc[9] += ay * bx; acc[10] += ay * by; acc[11] += ay * bz;
-		acc[12] += az * bx; acc[13] += az * by; acc[14] += az * bz;
-		acc[15] += d2;
+	if (valid) {
+		const float4 m = kd.pts[slot];
+		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
+		const float bx = m.x - st->cm[0], by = m.y - st->cm[1], bz = m.z - st->cm[2];
+		acc[0] = ax; acc[1] = ay; acc[2] = az;
+		acc[3] = bx; acc[4] = by; acc[5] = bz;
+		acc[6] = ax * bx; acc[7] = ax * by; acc[8] = ax * bz;
+		acc[9] = ay * bx; acc[10] = ay * by; acc[11] = ay * bz;
+		acc[12] = az * bx; acc[13] = az * by; acc[14] = az * bz;
+		acc[15] = d2;
 	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) {
-		float s = wave_sum(acc[k]);
-		if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kIcpAcc + k] = s;
+		const float s = wave_sum(acc[k]);
+		if (lane == 0) red[wave][k] = s;
+	}
+	__syncthreads();
+	if (threadIdx.x < kIcpAcc) {
+		float s = red[0][threadIdx.x];
+#pragma unroll
+		for (int w = 1; w < kIcpThreads / 64; w++) s += red[w][threadIdx.x];
+		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = s;
 	}
 }
 
-// 16 waves, wave k sums component k over all blocks in double, fixed order -> deterministic
-__global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize(const float* __restrict__ partials, int nblocks,
-                                                              double* __restrict__ out16)
+// ---- 3x3 SVD (one-sided Jacobi, double) -> Kabsch rotation, on the device ---------------------------
+__device__ void kabsch_rotation_dev(const double H[9], float R[9])
 {
+	double B[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, U[9], W[3];
+	for (int i = 0; i < 9; i++) B[i] = H[i];
+	for (int sweep = 0; sweep < 64; sweep++) {
+		double off = 0;
+		for (int p = 0; p < 2; p++)
+			for (int q = p + 1; q < 3; q++) {
+				double app = 0, aqq = 0, apq = 0;
+				for (int i = 0; i < 3; i++) {
+					app += B[3 * i + p] * B[3 * i + p];
+					aqq += B[3 * i + q] * B[3 * i + q];
+					apq += B[3 * i + p] * B[3 * i + q];
+				}
+				off += apq * apq;
+				if (apq == 0.0 || fabs(apq) <= 1e-17 * sqrt(app * aqq)) continue;
+				const double zeta = (aqq - app) / (2 * apq);
+				const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+				const double cs = 1 / sqrt(1 + tn * tn), sn = cs * tn;
+				for (int i = 0; i < 3; i++) {
+					const double bp = B[3 * i + p], bq = B[3 * i + q];
+					B[3 * i + p] = cs * bp - sn * bq;
+					B[3 * i + q] = sn * bp + cs * bq;
+					const double vp = V[3 * i + p], vq = V[3 * i + q];
+					V[3 * i + p] = cs * vp - sn * vq;
+					V[3 * i + q] = sn * vp + cs * vq;
+				}
+			}
+		if (off < 1e-60) break;
+	}
+	for (int j = 0; j < 3; j++) {
+		const double n = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+		W[j] = n;
+		for (int i = 0; i < 3; i++) U[3 * i + j] = n > 0 ? B[3 * i + j] / n : 0.0;
+	}
+	for (int j = 0; j < 3; j++) {          // rank-2 input: complete the missing left vector
+		if (W[j] > 1e-200) continue;
+		const int a = (j + 1) % 3, b = (j + 2) % 3;
+		if (W[a] <= 1e-200 || W[b] <= 1e-200) continue;
+		U[j] = U[3 + a] * U[6 + b] - U[6 + a] * U[3 + b];
+		U[3 + j] = U[6 + a] * U[b] - U[a] * U[6 + b];
+		U[6 + j] = U[a] * U[3 + b] - U[3 + a] * U[b];
+	}
+	double VUt[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			double s = 0;
+			for (int k = 0; k < 3; k++) s += V[3 * i + k] * U[3 * j + k];
+			VUt[3 * i + j] = s;
+		}
+	const double det = VUt[0] * (VUt[4] * VUt[8] - VUt[5] * VUt[7]) - VUt[1] * (VUt[3] * VUt[8] - VUt[5] * VUt[6]) +
+	                   VUt[2] * (VUt[3] * VUt[7] - VUt[4] * VUt[6]);
+	// the reference sorts singular values in decreasing order (matrix.cpp:782-808): its diag(1,1,det)
+	// (jly_icp3d.hpp:268-285) corrects the direction of the smallest one
+	int ks = 0;
+	if (W[1] < W[ks]) ks = 1;
+	if (W[2] < W[ks]) ks = 2;
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			double s = 0;
+			for (int k = 0; k < 3; k++) s += V[3 * i + k] * (k == ks ? det : 1.0) * U[3 * j + k];
+			R[3 * i + j] = (float)s;
+		}
+}
+
+// Sum the per-wave partials in double (fixed order -> deterministic), then -- one lane -- the body of
+// the ICP loop after the correspondence pass (jly_icp3d.hpp:253-292): convergence test, means, H,
+// SVD, R_ / t_, compose.  The pose lives in device memory, so the host can queue several iterations
+// back-to-back without a round trip.
+__global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
+                                                                     IcpState* __restrict__ st)
+{
+	if (st->converged) return;
+	__shared__ double sums[kIcpAcc];
 	const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	double s = 0.0;
 	for (int b = lane; b < nblocks; b += 64) s += (double)partials[(size_t)b * kIcpAcc + k];
 	s = wave_sum_d(s);
-	if (lane == 0) out16[k] = s;
+	if (lane == 0) sums[k] = s;
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	const float err_new = (float)sums[15];
+	st->err_new = err_new;
+	st->passes += 1;
+	if (st->frozen) return;                                                  // timing / scoring only
+	if (st->err > 0.f && st->err - err_new < st->err_diff_n) { st->converged = 1; return; }   // jly_icp3d.hpp:255
+	st->err = err_new;
+	const double nn = (double)st->n;
+	double alpha[3], beta[3];
+	float mu_d[3], mu_m[3];
+	for (int a = 0; a < 3; a++) {
+		const double sum_q = sums[a] + nn * (double)st->cq[a];
+		const double sum_m = sums[3 + a] + nn * (double)st->cm[a];
+		// jly_icp3d.hpp:244-263: the reference accumulates on top of the previous means and divides by n
+		const double carry_d = st->carry_means ? (double)st->mu_d[a] : 0.0;
+		const double carry_m = st->carry_means ? (double)st->mu_m[a] : 0.0;
+		mu_d[a] = (float)((carry_d + sum_q) / nn);
+		mu_m[a] = (float)((carry_m + sum_m) / nn);
+		st->mu_d[a] = mu_d[a]; st->mu_m[a] = mu_m[a];
+		alpha[a] = (double)mu_d[a] - (double)st->cq[a];
+		beta[a] = (double)mu_m[a] - (double)st->cm[a];
+	}
+	double H[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			const double h = sums[6 + 3 * i + j] - alpha[i] * sums[3 + j] - sums[i] * beta[j] + nn * alpha[i] * beta[j];
+			H[3 * i + j] = (double)(float)h;                                  // the reference holds H in float
+		}
+	float R_[9], t_[3], Rn[9], tn[3];
+	kabsch_rotation_dev(H, R_);
+	for (int i = 0; i < 3; i++) {
+		float acc = 0.f;
+		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * mu_d[a];
+		t_[i] = mu_m[i] - acc;                                                // t_ = mu_m - R_ mu_d
+	}
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) {
+			float acc = 0.f;
+			for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st->R[3 * a + j];
+			Rn[3 * i + j] = acc;                                              // R <- R_ R
+		}
+		float acc = 0.f;
+		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st->t[a];
+		tn[i] = acc + t_[i];                                                  // t <- R_ t + t_
+	}
+	for (int i = 0; i < 9; i++) st->R[i] = Rn[i];
+	for (int i = 0; i < 3; i++) {
+		st->t[i] = tn[i];
+		st->cq[i] = Rn[3 * i] * st->src_centroid[0] + Rn[3 * i + 1] * st->src_centroid[1] + Rn[3 * i + 2] * st->src_centroid[2] + tn[i];
+	}
+	st->iters += 1;
 }
 
-int icp_blocks(int N)
-{
-	int b = (N + kIcpThreads - 1) / kIcpThreads;
-	return b > 8192 ? 8192 : (b < 1 ? 1 : b);
-}
+int icp_blocks(int N) { return (N + kIcpThreads - 1) / kIcpThreads; }
 
-hipError_t launch_icp_pass(const float4* src, int N, const Pose& pose, const KdDesc& kd, const float cq[3],
-                           const float cm[3], float* partials, double* out16, hipStream_t stream)
+hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
+                                hipStream_t stream)
 {
-	int nb = icp_blocks(N);
-	hipLaunchKernelGGL(icp_pass_kernel, dim3(nb), dim3(kIcpThreads), 0, stream, src, N, pose, kd,
-	                   cq[0], cq[1], cq[2], cm[0], cm[1], cm[2], partials);
-	hipLaunchKernelGGL(icp_finalize, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, nb, out16);
+	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
+	const bool all = kd.L <= kLdsNodes;
+	if (all && dt.layout) hipLaunchKernelGGL((icp_pass_kernel<true, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	else if (all) hipLaunchKernelGGL((icp_pass_kernel<true, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<false, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	else hipLaunchKernelGGL((icp_pass_kernel<false, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, (int)grid.x, st);
 	return hipGetLastError();
 }
 
@@ -337,21 +534,29 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 	return hipGetLastError();
 }
 
-__global__ void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, int32_t* __restrict__ idx,
-                                float* __restrict__ d2)
+template <bool kAllLds, int LAYOUT>
+__global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, DtDesc dt,
+                                                               int32_t* __restrict__ idx, float* __restrict__ d2)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	float best, mx, my, mz; int id;
-	kd_nearest(kd, q[3 * i], q[3 * i + 1], q[3 * i + 2], best, id, mx, my, mz);
-	idx[i] = id;
-	d2[i] = best;
+	__shared__ uint2 lds_nodes[kLdsNodes * 3];
+	stage_nodes(kd, lds_nodes);
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int j = i < n ? i : n - 1;
+	const float qx = q[3 * j], qy = q[3 * j + 1], qz = q[3 * j + 2];
+	float best; int id, slot;
+	kd_nearest<kAllLds>(kd, lds_nodes, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz), best, id, slot);
+	if (i < n) { idx[i] = id; d2[i] = best; }
 }
 
-hipError_t launch_nn_query(const float* q, int n, const KdDesc& kd, int32_t* idx, float* d2, hipStream_t stream)
+hipError_t launch_nn_query(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
 {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(nn_query_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, q, n, kd, idx, d2);
+	const dim3 grid((n + kIcpThreads - 1) / kIcpThreads), block(kIcpThreads);
+	const bool all = kd.L <= kLdsNodes;
+	if (all && dt.layout) hipLaunchKernelGGL((nn_query_kernel<true, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
+	else if (all) hipLaunchKernelGGL((nn_query_kernel<true, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
+	else if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<false, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
+	else hipLaunchKernelGGL((nn_query_kernel<false, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 	return hipGetLastError();
 }
 

@@ -31,14 +31,19 @@ static_assert(sizeof(CubeRec) == 24, "CubeRec layout");
 
 struct Rot9 { float r[9]; };   // row-major
 
-// Implicit, left-balanced k-d tree over the target cloud ("flattened k-d tree").
-// Heap indexing: root = 1, children of n are 2n and 2n+1, leaves are nodes [L, 2L).
+// Flattened k-d tree over the target cloud: implicit, left-balanced, heap indexed --
+// root = 1, children of n are 2n and 2n+1, leaves are nodes [L, 2L).  Internal node n carries the
+// tight bounding boxes of its two children, 16-bit quantised against the root box with conservative
+// rounding: 3 x uint2 = {Lx, Ly | Lz, Rx | Ry, Rz}, each word lo | hi << 16.  Leaf l owns the
+// kLeafSlots consecutive float4 slots pts[kLeafSlots*l ...] (aligned 128-B lines); unused slots hold
+// +inf coordinates with index INT_MAX, so they never win.
+constexpr int kLeafSlots = 16;
 struct KdDesc {
-	const float2* nodes;      // [L]  (.x = split value, .y = split dim as int bits); entry 0 unused
-	const float4* pts;        // [M]  leaf order; .w = original index (int bits)
-	const int32_t* leaf_start; // [L+1]
+	const uint2* boxes;       // [3*L]; entries of node 0 unused
+	const float4* pts;        // [kLeafSlots*L]  leaf order; .w = original index (int bits)
 	int L;                    // number of leaves (power of two)
 	int M;
+	float root_lo[3], step[3]; // box coordinate = root_lo + code * step
 };
 
 struct Pose { float R[9]; float t[3]; };
@@ -54,16 +59,30 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream);
 
 // ---- ICP ------------------------------------------------------------------------------------
-// One pass: q_i = R p_i + t, exact 1-NN in the k-d tree, pivoted sums -> out16 (double[16]).
-// partials must hold icp_blocks(N)*kIcpAcc floats.
-int icp_blocks(int N);
-hipError_t launch_icp_pass(const float4* src, int N, const Pose& pose, const KdDesc& kd,
-                           const float cq[3], const float cm[3], float* partials, double* out16,
-                           hipStream_t stream);
+// Device-resident state of the ICP loop (ICP3D<float>::Run, jly_icp3d.hpp:181-295).  One
+// iteration = icp_pass_kernel (transform, exact 1-NN, pivoted sums) + icp_finalize_update
+// (double-precision reduction, convergence test, SVD, pose update); iterations can be queued
+// back-to-back, a converged state turns the remaining launches into no-ops.
+struct IcpState {
+	float R[9], t[3];            // current pose
+	float mu_m[3], mu_d[3];      // means carried across iterations (jly_icp3d.hpp:205-206,244-263)
+	float cq[3], cm[3];          // pivots of the next pass (current centroids)
+	float src_centroid[3];
+	float err, err_new;          // previous / last pass: sum of squared NN distances
+	float err_diff_n;            // err_diff * num (jly_icp3d.hpp:255)
+	float n;                     // number of source points
+	int32_t converged, iters, passes;
+	int32_t carry_means;         // 1: the reference's carried means; 0: fresh means (single-step API)
+	int32_t frozen;              // 1: passes only score, the pose is not updated
+};
+int icp_blocks(int N);           // workgroups per pass; partials must hold icp_blocks(N)*kIcpAcc floats
+hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
+                                float* partials, hipStream_t stream);
 // In-place p <- R p + t, norm recomputed (ICP::kdTreeGPUStep's kernTransform, icp_kernel.cu:138-144)
 hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t stream);
 // NN operator on arbitrary queries (kernKDSearchNearest, icp_kernel.cu:146-157)
-hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, int32_t* idx, float* d2, hipStream_t stream);
+hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2,
+                           hipStream_t stream);
 
 // ---- distance transform build (DT3D::Build, jly_3ddt.cpp:889-979; exact EDT) -------------------
 // work: V^3 int32 (linear).  out: V^3 floats in dt.layout (may alias work only for layout 0).

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -189,18 +190,17 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	// ---- k-d tree over the target ----
 	{
 		KdHost kh;
-		build_kdtree(target, (int)M_, 8, &kh);
-		HIPCHK(hipMalloc(&d_kd_nodes_, sizeof(float2) * kh.nodes.size()));
+		build_kdtree(target, (int)M_, kLeafSlots, &kh);
+		HIPCHK(hipMalloc(&d_kd_boxes_, sizeof(uint2) * kh.boxes.size()));
 		HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
-		HIPCHK(hipMalloc(&d_kd_leaf_, sizeof(int32_t) * kh.leaf_start.size()));
-		HIPCHK(hipMemcpy(d_kd_nodes_, kh.nodes.data(), sizeof(float2) * kh.nodes.size(), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d_kd_boxes_, kh.boxes.data(), sizeof(uint2) * kh.boxes.size(), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(d_kd_leaf_, kh.leaf_start.data(), sizeof(int32_t) * kh.leaf_start.size(), hipMemcpyHostToDevice));
-		kd_.nodes = d_kd_nodes_; kd_.pts = d_kd_pts_; kd_.leaf_start = d_kd_leaf_; kd_.L = kh.L; kd_.M = (int)M_;
+		kd_.boxes = d_kd_boxes_; kd_.pts = d_kd_pts_; kd_.L = kh.L; kd_.M = (int)M_;
+		for (int k = 0; k < 3; k++) { kd_.root_lo[k] = kh.root_lo[k]; kd_.step[k] = kh.step[k]; }
 	}
 	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)icp_blocks((int)N_) * kIcpAcc));
-	HIPCHK(hipMalloc(&d_icp_out_, sizeof(double) * kIcpAcc));
-	HIPCHK(hipHostMalloc(&h_icp_out_, sizeof(double) * kIcpAcc));
+	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
+	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState)));
 	ensure_batch(4096, 64);
 
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -213,10 +213,10 @@ Engine::~Engine()
 {
 	hipStreamSynchronize(stream_);
 	hipFree(d_src_); hipFree(d_dt_);
-	hipFree(d_kd_nodes_); hipFree(d_kd_pts_); hipFree(d_kd_leaf_);
+	hipFree(d_kd_boxes_); hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
-	hipFree(d_icp_partials_); hipFree(d_icp_out_); hipHostFree(h_icp_out_);
+	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_);
 	hipEventDestroy(ev0_); hipEventDestroy(ev1_);
 	hipStreamDestroy(stream_);
 }
@@ -355,7 +355,7 @@ void Engine::nn_query(const float* q, size_t n, int32_t* idx, float* d2)
 	HIPCHK(hipMalloc(&di, sizeof(int32_t) * n));
 	HIPCHK(hipMalloc(&dd, sizeof(float) * n));
 	HIPCHK(hipMemcpyAsync(dq, q, sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream_));
-	HIPCHK(launch_nn_query(dq, (int)n, kd_, di, dd, stream_));
+	HIPCHK(launch_nn_query(dq, (int)n, kd_, dt_, di, dd, stream_));
 	HIPCHK(hipMemcpyAsync(idx, di, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipMemcpyAsync(d2, dd, sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
@@ -375,91 +375,63 @@ void Engine::source_transformed(const float R[9], const float t[3], float* out)
 
 // ------------------------------------------------------------------------------------------------
 // ICP (ICP3D<float>::Run, jly_icp3d.hpp:181-295; IterativeClosestPoint3D::run, fgoicp/icp3d.cu:83-108)
+// The loop state lives on the device (IcpState); iterations are queued in chunks without a host
+// round trip, a converged state turns the queued remainder into no-ops.
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct IcpState { float mu_m[3] = {0, 0, 0}, mu_d[3] = {0, 0, 0}; };   // carried across iterations as the reference does
-
-// host part of one iteration: sums -> (R_, t_) -> composed pose
-void icp_update(const double s[16], size_t n, const float cq[3], const float cm[3], IcpState& st, float R[9], float t[3])
+void Engine::icp_state_init(const float R[9], const float t[3], float err_diff, int carry_means, int frozen)
 {
-	const double nn = (double)n;
-	double alpha[3], beta[3];
-	for (int k = 0; k < 3; k++) {
-		double sum_q = s[k] + nn * (double)cq[k];
-		double sum_m = s[3 + k] + nn * (double)cm[k];
-		// jly_icp3d.hpp:244-263: the means are accumulated on top of the previous means and divided by n
-		st.mu_d[k] = (float)(((double)st.mu_d[k] + sum_q) / nn);
-		st.mu_m[k] = (float)(((double)st.mu_m[k] + sum_m) / nn);
-		alpha[k] = (double)st.mu_d[k] - (double)cq[k];
-		beta[k] = (double)st.mu_m[k] - (double)cm[k];
-	}
-	// H = sum (q - mu_d)(m - mu_m)^T from the pivoted sums
-	double H[9];
-	for (int i = 0; i < 3; i++)
-		for (int j = 0; j < 3; j++)
-			H[3 * i + j] = s[6 + 3 * i + j] - alpha[i] * s[3 + j] - s[i] * beta[j] + nn * alpha[i] * beta[j];
-	for (int k = 0; k < 9; k++) H[k] = (double)(float)H[k];   // the reference holds H in float
-	float R_[9];
-	kabsch_rotation(H, R_);
-	float t_[3];
+	IcpState& st = *h_icp_state_;
+	std::memset(&st, 0, sizeof(st));
+	std::memcpy(st.R, R, sizeof(st.R));
+	std::memcpy(st.t, t, sizeof(st.t));
 	for (int i = 0; i < 3; i++) {
-		float acc = 0.f;
-		for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * st.mu_d[k];
-		t_[i] = st.mu_m[i] - acc;                       // t_ = mu_m - R_ mu_d
+		st.src_centroid[i] = src_centroid_[i];
+		st.cm[i] = model_centroid_[i];
+		st.cq[i] = R[3 * i] * src_centroid_[0] + R[3 * i + 1] * src_centroid_[1] + R[3 * i + 2] * src_centroid_[2] + t[i];
 	}
-	float Rn[9], tn[3];
-	for (int i = 0; i < 3; i++) {
-		for (int j = 0; j < 3; j++) {
-			float acc = 0.f;
-			for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * R[3 * k + j];
-			Rn[3 * i + j] = acc;                        // R <- R_ R
-		}
-		float acc = 0.f;
-		for (int k = 0; k < 3; k++) acc += R_[3 * i + k] * t[k];
-		tn[i] = acc + t_[i];                            // t <- R_ t + t_
-	}
-	std::memcpy(R, Rn, sizeof(Rn));
-	std::memcpy(t, tn, sizeof(tn));
+	st.err = -1.f;
+	st.err_diff_n = err_diff * (float)N_;          // jly_icp3d.hpp:255: err_diff * num
+	st.n = (float)N_;
+	st.carry_means = carry_means;
+	st.frozen = frozen;
+	HIPCHK(hipMemcpyAsync(d_icp_state_, h_icp_state_, sizeof(IcpState), hipMemcpyHostToDevice, stream_));
 }
-}  // namespace
+
+void Engine::icp_state_fetch()
+{
+	HIPCHK(hipMemcpyAsync(h_icp_state_, d_icp_state_, sizeof(IcpState), hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+}
 
 float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters_out)
 {
-	IcpState st;
-	float err = -1.f, err_new = 0.f;
-	int iter = 0;
-	Pose pose;
-	for (iter = 0; iter < max_iter; iter++) {
-		std::memcpy(pose.R, R, sizeof(pose.R));
-		std::memcpy(pose.t, t, sizeof(pose.t));
-		float cq[3];
-		for (int i = 0; i < 3; i++) cq[i] = R[3 * i] * src_centroid_[0] + R[3 * i + 1] * src_centroid_[1] + R[3 * i + 2] * src_centroid_[2] + t[i];
-		HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
-		HIPCHK(hipMemcpyAsync(h_icp_out_, d_icp_out_, sizeof(double) * kIcpAcc, hipMemcpyDeviceToHost, stream_));
-		HIPCHK(hipStreamSynchronize(stream_));
-		err_new = (float)h_icp_out_[15];
-		if (err > 0 && err - err_new < err_diff * (float)N_) break;    // jly_icp3d.hpp:255
-		err = err_new;
-		icp_update(h_icp_out_, N_, cq, model_centroid_, st, R, t);
-		if (cancel_.load()) { iter++; break; }
+	icp_state_init(R, t, err_diff, 1, 0);
+	const int chunk = std::max(1, p_.icp_chunk);
+	int queued = 0;
+	while (queued < max_iter) {
+		const int k = std::min(chunk, max_iter - queued);
+		for (int i = 0; i < k; i++) HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+		queued += k;
+		icp_state_fetch();
+		if (h_icp_state_->converged || cancel_.load()) break;
 	}
-	if (iters_out) *iters_out = iter;
-	cnt_.icp_iters += iter;
+	if (max_iter <= 0) icp_state_fetch();
+	const IcpState& st = *h_icp_state_;
+	std::memcpy(R, st.R, sizeof(st.R));
+	std::memcpy(t, st.t, sizeof(st.t));
+	if (iters_out) *iters_out = st.iters;
+	cnt_.icp_iters += st.passes;
 	cnt_.icp_runs++;
-	return err_new;
+	return st.err_new;
 }
 
 float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
 {
-	Pose pose;
-	std::memcpy(pose.R, R, sizeof(pose.R));
-	std::memcpy(pose.t, t, sizeof(pose.t));
-	float cq[3] = {0, 0, 0};
-	HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+	icp_state_init(R, t, 0.f, 0, 1);   // frozen: every pass does the same work
+	HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
 	HIPCHK(hipEventRecord(ev0_, stream_));
-	for (int i = 0; i < iters; i++)
-		HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
+	for (int i = 0; i < iters; i++) HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
 	HIPCHK(hipEventRecord(ev1_, stream_));
 	HIPCHK(hipEventSynchronize(ev1_));
 	float ms = 0.f;
@@ -470,23 +442,18 @@ float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
 void Engine::icp_step()
 {
 	// one iteration from the current step pose, fresh means, standard Kabsch (icp_kernel.cu:219-279)
-	IcpState st;
-	Pose pose;
-	std::memcpy(pose.R, stepR_, sizeof(pose.R));
-	std::memcpy(pose.t, stepT_, sizeof(pose.t));
-	float cq[3];
-	for (int i = 0; i < 3; i++) cq[i] = stepR_[3 * i] * src_centroid_[0] + stepR_[3 * i + 1] * src_centroid_[1] + stepR_[3 * i + 2] * src_centroid_[2] + stepT_[i];
-	HIPCHK(launch_icp_pass(d_src_, (int)N_, pose, kd_, cq, model_centroid_, d_icp_partials_, d_icp_out_, stream_));
-	HIPCHK(hipMemcpyAsync(h_icp_out_, d_icp_out_, sizeof(double) * kIcpAcc, hipMemcpyDeviceToHost, stream_));
-	HIPCHK(hipStreamSynchronize(stream_));
-	icp_update(h_icp_out_, N_, cq, model_centroid_, st, stepR_, stepT_);
+	icp_state_init(stepR_, stepT_, 0.f, 0, 0);
+	HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+	icp_state_fetch();
+	std::memcpy(stepR_, h_icp_state_->R, sizeof(stepR_));
+	std::memcpy(stepT_, h_icp_state_->t, sizeof(stepT_));
 	cnt_.icp_iters++;
 	std::lock_guard<std::mutex> lk(mtx_);
 	std::memcpy(snap_.curR, stepR_, sizeof(stepR_));
 	std::memcpy(snap_.curT, stepT_, sizeof(stepT_));
 	std::memcpy(snap_.optR, stepR_, sizeof(stepR_));
 	std::memcpy(snap_.optT, stepT_, sizeof(stepT_));
-	snap_.best_sse = (float)h_icp_out_[15];
+	snap_.best_sse = h_icp_state_->err_new;
 	snap_.counters = cnt_;
 }
 

@@ -25,6 +25,7 @@ struct Params {
 	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
 	int verbose = 0;
 	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
+	int icp_chunk = 16;           // ICP iterations queued per host round trip
 };
 
 struct Counters {
@@ -110,6 +111,8 @@ private:
 	void adopt(float err, const float R[9], const float t[3]);
 	float icp_from(float R[9], float t[3]);
 	void publish(bool finished);
+	void icp_state_init(const float R[9], const float t[3], float err_diff, int carry_means, int frozen);
+	void icp_state_fetch();
 
 	Params p_;
 	size_t M_ = 0, N_ = 0;
@@ -126,7 +129,7 @@ private:
 	float* d_dt_ = nullptr;
 	// k-d tree
 	KdDesc kd_{};
-	float2* d_kd_nodes_ = nullptr; float4* d_kd_pts_ = nullptr; int32_t* d_kd_leaf_ = nullptr;
+	uint2* d_kd_boxes_ = nullptr; float4* d_kd_pts_ = nullptr;
 	// bounds staging
 	size_t cap_cubes_ = 0, cap_rots_ = 0, cap_scratch_ = 0;
 	CubeRec* d_cubes_ = nullptr; CubeRec* h_cubes_ = nullptr;
@@ -134,7 +137,7 @@ private:
 	float* d_ub_ = nullptr; float* d_lb_ = nullptr; float* h_ub_ = nullptr; float* h_lb_ = nullptr;
 	float* d_scratch_ = nullptr;
 	// icp staging
-	float* d_icp_partials_ = nullptr; double* d_icp_out_ = nullptr; double* h_icp_out_ = nullptr;
+	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
 	// nn query staging grows on demand
 	float rot_coeff_[20];
 
@@ -154,10 +157,10 @@ private:
 
 // ---- host utilities (config_io.cpp, kdtree.cpp) ----
 struct KdHost {
-	std::vector<float2> nodes; std::vector<float4> pts; std::vector<int32_t> leaf_start; int L = 1;
+	std::vector<uint2> boxes; std::vector<float4> pts; int L = 1;   // boxes: 3 words per node; pts: kLeafSlots slots per leaf
+	float root_lo[3] = {0, 0, 0}, step[3] = {1, 1, 1};
 };
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
-void kabsch_rotation(const double H[9], float R[9]);   // R_ = V diag(1,1,det(V U^T)) U^T (jly_icp3d.hpp:268-285)
 void rodrigues(float v1, float v2, float v3, float R[9]);   // jly_goicp.cpp:449-467
 
 }  // namespace goicp

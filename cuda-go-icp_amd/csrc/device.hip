@@ -53,22 +53,44 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 template <int LAYOUT>
 __device__ __forceinline__ float dt_fetch(const DtDesc& dt, int x, int y, int z)
 {
+	// 24-bit multiplies (full rate) and a 32-bit byte offset from a scalar base: V <= 640 keeps
+	// every offset below 2^32 (engine.cpp enforces it)
+	unsigned e;
 	if (LAYOUT == 0) {
-		return dt.grid[((size_t)z * dt.V + y) * dt.V + x];
+		e = __umul24(__umul24((unsigned)z, (unsigned)dt.V) + (unsigned)y, (unsigned)dt.V) + (unsigned)x;
 	} else {
-		size_t b = ((size_t)(z >> 2) * dt.VB + (y >> 2)) * dt.VB + (x >> 2);
-		int in = ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
-		return dt.grid[b * 64 + in];
+		const unsigned b = __umul24(__umul24((unsigned)z >> 2, (unsigned)dt.VB) + ((unsigned)y >> 2), (unsigned)dt.VB) + ((unsigned)x >> 2);
+		e = (b << 6) | ((((unsigned)z & 3u) << 4) | (((unsigned)y & 3u) << 2) | ((unsigned)x & 3u));
 	}
+	return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
+}
+
+// voxel index of one coordinate: the reference computes int((double(q) - min)*scale + 0.5) in double
+// (jly_3ddt.cpp:984-986).  Fast path: the same expression in float (1 sub + 1 fma) is within
+// eps(F) = c1 + c2*|F| of the exact value (rounding of min, scale, the difference and the fma;
+// DtDesc.c1/c2 are computed on the host from the grid geometry); whenever F is farther than eps
+// from the nearest integer, truncating F gives the reference's index.  Otherwise -- a few lanes
+// in 10^4 -- the caller recomputes in double.  Result: bit-identical indices at ~1/3 of the cost.
+__device__ __forceinline__ int voxel_fast(float q, float mn, float scale, float c1, float c2, bool& risky)
+{
+	const float F = __fmaf_rn(q - mn, scale, 0.5f);
+	risky = risky || (fabsf(F - rintf(F)) <= __fmaf_rn(fabsf(F), c2, c1));
+	return (int)F;
 }
 
 template <int LAYOUT>
 __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float qy, float qz)
 {
-	// double index math exactly as the reference: (x - xMin)*scale + 0.5, truncate
-	int x = (int)(((double)qx - dt.xmin) * dt.scale + 0.5);
-	int y = (int)(((double)qy - dt.ymin) * dt.scale + 0.5);
-	int z = (int)(((double)qz - dt.zmin) * dt.scale + 0.5);
+	bool risky = false;
+	int x = voxel_fast(qx, dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+	int y = voxel_fast(qy, dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
+	int z = voxel_fast(qz, dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+	if (risky) {
+		// double index math exactly as the reference: (x - xMin)*scale + 0.5, truncate
+		x = (int)(((double)qx - dt.xmin) * dt.scale + 0.5);
+		y = (int)(((double)qy - dt.ymin) * dt.scale + 0.5);
+		z = (int)(((double)qz - dt.zmin) * dt.scale + 0.5);
+	}
 	const int V = dt.V;
 	if ((unsigned)x < (unsigned)V && (unsigned)y < (unsigned)V && (unsigned)z < (unsigned)V)
 		return dt_fetch<LAYOUT>(dt, x, y, z);
@@ -79,6 +101,29 @@ __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float q
 	if (z < 0) { c = (float)z; z = 0; } else if (z >= V) { c = (float)(z - V + 1); z = V - 1; }
 	float r = __fsqrt_rn(a * a + b * b + c * c);
 	return (float)((double)r / dt.scale + (double)dt_fetch<LAYOUT>(dt, x, y, z));
+}
+
+// Per-axis part of a voxel's element offset.  Both layouts are separable: offset = fx(x)+fy(y)+fz(z);
+// an out-of-grid index contributes kOutside (>= 2^30 > any in-grid sum, and three of them do not wrap),
+// so one unsigned compare of the sum tells whether the fast fetch is valid.
+constexpr unsigned kOutside = 0x40000000u;
+template <int LAYOUT, int AXIS>
+__device__ __forceinline__ unsigned axis_term(const DtDesc& dt, float q)
+{
+	const float mn_f = AXIS == 0 ? dt.xmin_f : (AXIS == 1 ? dt.ymin_f : dt.zmin_f);
+	bool risky = false;
+	int i = voxel_fast(q, mn_f, dt.scale_f, dt.c1, dt.c2, risky);
+	if (risky) {
+		const double mn = AXIS == 0 ? dt.xmin : (AXIS == 1 ? dt.ymin : dt.zmin);
+		i = (int)(((double)q - mn) * dt.scale + 0.5);
+	}
+	if ((unsigned)i >= (unsigned)dt.V) return kOutside;
+	const unsigned u = (unsigned)i;
+	if (LAYOUT == 0) return AXIS == 0 ? u : (AXIS == 1 ? __umul24(u, (unsigned)dt.V) : __umul24(u, (unsigned)(dt.V * dt.V)));
+	const unsigned hi = u >> 2, lo = u & 3u;
+	if (AXIS == 0) return (hi << 6) | lo;
+	if (AXIS == 1) return (__umul24(hi, (unsigned)dt.VB) << 6) | (lo << 2);
+	return (__umul24(hi, (unsigned)(dt.VB * dt.VB)) << 6) | (lo << 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -94,8 +139,19 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const CubeRec* __restrict__ cubes, int B, int groups, int chunks, int chunk_pts,
     float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
-	const int swz = xcd_remap(blockIdx.x, gridDim.x);
-	const int chunk = swz / groups, group = swz - chunk * groups;
+	// XCD-aware tiling (speed only): blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns
+	// the point chunks [x*cpx, (x+1)*cpx) -- a compact spatial patch of the Morton-sorted cloud -- and
+	// walks the cube groups in order, so at any time one L2 serves gathers into the DT neighbourhood
+	// of ONE patch under nearby translations (a few MB) instead of the whole surface band.
+	int chunk, group;
+	if ((chunks & 7) == 0) {
+		const int cpx = chunks >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+		group = slot / cpx;
+		chunk = xcd * cpx + (slot - group * cpx);
+	} else {
+		const int swz = xcd_remap(blockIdx.x, gridDim.x);
+		chunk = swz / groups; group = swz - chunk * groups;
+	}
 	const int c0 = group * kGroup;
 
 	CubeRec cr[kGroup];
@@ -107,6 +163,13 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 		uniform = uniform && (cr[c].rot == cr[0].rot);
 	}
 	const Rot9 R0 = rots[cr[0].rot];
+	// The 8 children of one BnB expansion share, per axis, only TWO translation values
+	// (jly_goicp.cpp:267-273: corner + (j>>a & 1)*w + w/2), one rotation, one delta, one coeff.
+	bool siblings = uniform && c0 + kGroup <= B;
+#pragma unroll
+	for (int c = 0; c < kGroup; c++)
+		siblings = siblings && cr[c].tx == cr[c & 1].tx && cr[c].ty == cr[c & 2].ty && cr[c].tz == cr[c & 4].tz &&
+		           cr[c].delta == cr[0].delta && cr[c].coeff == cr[0].coeff;
 
 	float ub[kGroup], lb[kGroup];
 #pragma unroll
@@ -114,6 +177,35 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 
 	const int p0 = chunk * chunk_pts;
 	const int p1 = p0 + chunk_pts < N ? p0 + chunk_pts : N;
+	if (siblings) {
+		// fast path: 6 voxel-index computations per point instead of 24; every per-point value is the
+		// same float expression as in the generic path below, so the results are bit-identical
+		const float tx0 = cr[0].tx, tx1 = cr[1].tx, ty0 = cr[0].ty, ty1 = cr[2].ty, tz0 = cr[0].tz, tz1 = cr[4].tz;
+		const float delta = cr[0].delta, coeff = cr[0].coeff;
+		for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
+			const float4 p = src[i];
+			const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
+			const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
+			const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+			const float rho = coeff * p.w;
+			const float qx[2] = {rx + tx0, rx + tx1}, qy[2] = {ry + ty0, ry + ty1}, qz[2] = {rz + tz0, rz + tz1};
+			const unsigned fx[2] = {axis_term<LAYOUT, 0>(dt, qx[0]), axis_term<LAYOUT, 0>(dt, qx[1])};
+			const unsigned fy[2] = {axis_term<LAYOUT, 1>(dt, qy[0]), axis_term<LAYOUT, 1>(dt, qy[1])};
+			const unsigned fz[2] = {axis_term<LAYOUT, 2>(dt, qz[0]), axis_term<LAYOUT, 2>(dt, qz[1])};
+#pragma unroll
+			for (int c = 0; c < kGroup; c++) {
+				const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
+				float m;
+				if (e < kOutside) m = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
+				else m = dt_distance<LAYOUT>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);   // clamp + overshoot extension
+				m = m - rho;
+				if (m < 0.f) m = 0.f;
+				ub[c] += m * m;
+				const float dis = fmaxf(m - delta, 0.f);
+				lb[c] += dis * dis;
+			}
+		}
+	} else
 	for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
 		const float4 p = src[i];
 		// p~ = R p (jly_goicp.cpp:470-476), left-to-right float sums
@@ -132,8 +224,8 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 			m = m - cr[c].coeff * p.w;          // rotation uncertainty radius (jly_goicp.cpp:284-285, :159)
 			if (m < 0.f) m = 0.f;
 			ub[c] += m * m;                      // :302-306
-			float dis = m - cr[c].delta;         // :312
-			if (dis > 0.f) lb[c] += dis * dis;
+			const float dis = fmaxf(m - cr[c].delta, 0.f);   // :312-314 (adding 0 when dis <= 0 is the same sum)
+			lb[c] += dis * dis;
 		}
 	}
 
@@ -176,15 +268,18 @@ __global__ void bounds_finalize(const float* __restrict__ scratch, int B, int gr
 static void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts)
 {
 	int g = (B + kGroup - 1) / kGroup;
-	// aim for >= 8 blocks of 256 threads per CU (256 CUs) so that the gathers have 32 waves/CU
+	// aim for >= 8 blocks of 256 threads per CU (256 CUs) so that the gathers have 32 waves/CU, and
+	// for a multiple of 8 point chunks (one set per XCD) whenever the cloud is large enough
 	const int target_blocks = 2048;
-	int max_chunks = (N + kBoundsThreads - 1) / kBoundsThreads;
+	const int max_chunks = (N + kBoundsThreads - 1) / kBoundsThreads;
 	int c = (target_blocks + g - 1) / g;
-	if (c > max_chunks) c = max_chunks;
+	if (max_chunks >= 8) c = (c + 7) / 8 * 8;
+	if (c > max_chunks) c = max_chunks >= 8 ? max_chunks / 8 * 8 : max_chunks;
 	if (c < 1) c = 1;
 	int cp = (N + c - 1) / c;
 	cp = (cp + kBoundsThreads - 1) / kBoundsThreads * kBoundsThreads;
-	c = (N + cp - 1) / cp;
+	int c2 = (N + cp - 1) / cp;                 // rounding the chunk size up may empty the last chunks
+	if ((c & 7) == 0 && c2 != c) { /* keep c: trailing chunks are simply empty */ } else c = c2;
 	*groups = g; *chunks = c; *chunk_pts = cp;
 }
 

@@ -18,6 +18,9 @@ struct DtDesc {
 	int layout;
 	double scale;   // voxels per unit                      (jly_3ddt.cpp:923)
 	double xmin, ymin, zmin;
+	// float images of the geometry + the error model of the float index fast path (device.hip voxel_fast)
+	float scale_f, xmin_f, ymin_f, zmin_f;
+	float c1, c2;   // |F_float - F_exact| <= c1 + c2*|F|
 };
 
 // One translation sub-cube to bound (the inner body of GoICP::InnerBnB, jly_goicp.cpp:262-315).

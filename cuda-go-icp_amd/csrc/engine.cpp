@@ -75,7 +75,7 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 {
 	if (!target || !source || M == 0 || N == 0) throw std::invalid_argument("goicp: empty target or source cloud");
 	if (M > (size_t)INT32_MAX / 8 || N > (size_t)INT32_MAX / 8) throw std::invalid_argument("goicp: cloud too large");
-	if (p_.dt_size < 8 || p_.dt_size > 1024) throw std::invalid_argument("goicp: dt_size must be in [8,1024]");
+	if (p_.dt_size < 8 || p_.dt_size > 640) throw std::invalid_argument("goicp: dt_size must be in [8,640]");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		throw std::runtime_error("goicp: no HIP device available (this engine has no CPU fallback)");
@@ -163,6 +163,12 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 		dt_.layout = p_.dt_layout ? 1 : 0;
 		dt_.xmin = xc - side / 2; dt_.ymin = yc - side / 2; dt_.zmin = zc - side / 2;
 		dt_.scale = dt_.V / side;
+		dt_.scale_f = (float)dt_.scale; dt_.xmin_f = (float)dt_.xmin; dt_.ymin_f = (float)dt_.ymin; dt_.zmin_f = (float)dt_.zmin;
+		// float index fast path: 2^-24 * (scale*|min| + 3|F| + 2) bounds the rounding of min_f, scale_f,
+		// (q - min_f) and the fma; shipped with a margin (4|F| + 8, x1.05)
+		const double s0 = dt_.scale * std::max({std::fabs(dt_.xmin), std::fabs(dt_.ymin), std::fabs(dt_.zmin)});
+		dt_.c1 = (float)(1.05 * std::ldexp(1.0, -24) * (s0 + 8.0));
+		dt_.c2 = (float)(1.05 * std::ldexp(1.0, -24) * 4.0);
 	}
 	// ---- DT build on the GPU ----
 	{
@@ -246,7 +252,7 @@ void Engine::ensure_batch(size_t B, size_t K)
 	}
 	size_t need = bounds_scratch_floats((int)std::max<size_t>(B, 1), (int)N_, nullptr, nullptr);
 	// the scratch need is not monotone in B (fewer cubes -> more point chunks): size for the worst case
-	size_t worst = (size_t)2 * kGroup * (size_t)(2048 + (cap_cubes_ + kGroup - 1) / kGroup + 64) * 2;
+	size_t worst = (size_t)2 * kGroup * (8 * ((cap_cubes_ + kGroup - 1) / kGroup) + 4096);   // groups x (<= 8 + 2048/groups) chunks
 	need = std::max(need, worst);
 	if (need > cap_scratch_) {
 		hipStreamSynchronize(stream_);

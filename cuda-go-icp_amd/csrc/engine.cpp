@@ -643,22 +643,24 @@ void Engine::register_begin()
 	publish(false);
 }
 
-void Engine::process_parent(const Node& parent)
+void Engine::process_parents(const std::vector<Node>& parents)
 {
 	struct Child { Node node; float R[9]; };
 	std::vector<Child> kids;
-	Node c{};
-	c.w = parent.w / 2;          // jly_goicp.cpp:427-428
-	c.l = parent.l + 1;
-	for (int j = 0; j < 8; j++) {
-		c.x = parent.x + (j & 1) * c.w; c.y = parent.y + (j >> 1 & 1) * c.w; c.z = parent.z + (j >> 2 & 1) * c.w;
-		float v1 = c.x + c.w / 2, v2 = c.y + c.w / 2, v3 = c.z + c.w / 2;
-		// pi-ball cull (:443): float sqrt, double subtraction and comparison
-		if ((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - kSQRT3 * (double)c.w / 2 > kPI) continue;
-		Child k;
-		k.node = c;
-		rodrigues(v1, v2, v3, k.R);
-		kids.push_back(k);
+	for (const Node& parent : parents) {
+		Node c{};
+		c.w = parent.w / 2;          // jly_goicp.cpp:427-428
+		c.l = parent.l + 1;
+		for (int j = 0; j < 8; j++) {
+			c.x = parent.x + (j & 1) * c.w; c.y = parent.y + (j >> 1 & 1) * c.w; c.z = parent.z + (j >> 2 & 1) * c.w;
+			float v1 = c.x + c.w / 2, v2 = c.y + c.w / 2, v3 = c.z + c.w / 2;
+			// pi-ball cull (:443): float sqrt, double subtraction and comparison
+			if ((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - kSQRT3 * (double)c.w / 2 > kPI) continue;
+			Child k;
+			k.node = c;
+			rodrigues(v1, v2, v3, k.R);
+			kids.push_back(k);
+		}
 	}
 	if (kids.empty()) return;
 	std::vector<Rot9> rots(kids.size());
@@ -702,20 +704,20 @@ void Engine::process_parent(const Node& parent)
 	};
 
 	if (p_.wide_children) {
-		// all children's upper-bound searches in lockstep, then all lower-bound searches
+		// every child's upper-bound AND lower-bound search in lock-step: one launch per round covers
+		// up to 16 searches per rotation parent.  The searches start from the incumbent of the batch
+		// start (the reference lets earlier children tighten it: fewer nodes, same bounds).
 		std::vector<InnerSearch> ubs, lbs;
 		ubs.reserve(kids.size()); lbs.reserve(kids.size());
+		for (size_t i = 0; i < kids.size(); i++) { ubs.push_back(fresh(i, 0.f)); lbs.push_back(fresh(i, rot_coeff(kids[i].node.l))); }
 		std::vector<InnerSearch*> ptr;
-		for (size_t i = 0; i < kids.size(); i++) { ubs.push_back(fresh(i, 0.f)); }
 		for (auto& s : ubs) ptr.push_back(&s);
-		run_inner(ptr, rots);
-		for (size_t i = 0; i < kids.size(); i++)
-			if (handle_ub(kids[i], ubs[i])) return;
-		ptr.clear();
-		for (size_t i = 0; i < kids.size(); i++) { lbs.push_back(fresh(i, rot_coeff(kids[i].node.l))); }
 		for (auto& s : lbs) ptr.push_back(&s);
 		run_inner(ptr, rots);
-		for (size_t i = 0; i < kids.size(); i++) handle_lb(kids[i], lbs[i]);
+		for (size_t i = 0; i < kids.size(); i++) {
+			if (handle_ub(kids[i], ubs[i])) return;
+			handle_lb(kids[i], lbs[i]);
+		}
 	} else {
 		for (size_t i = 0; i < kids.size(); i++) {
 			InnerSearch u = fresh(i, 0.f);
@@ -734,17 +736,23 @@ void Engine::process_parent(const Node& parent)
 StepStatus Engine::register_step(int max_rot_pops)
 {
 	int pops = 0;
+	const int P = p_.wide_children ? std::max(1, p_.rot_batch) : 1;
 	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
-		Node parent = queue_.top();
-		queue_.pop();
-		cnt_.rot_pops++;
-		pops++;
-		if ((opt_err_ - parent.lb) <= sse_thresh_) {          // jly_goicp.cpp:416
-			// single rank: global convergence.  sharded: this rank's frontier can no longer improve
-			converged_ = true;
-			break;
+		std::vector<Node> parents;
+		while ((int)parents.size() < P && !queue_.empty() && pops < max_rot_pops) {
+			Node parent = queue_.top();
+			if ((opt_err_ - parent.lb) <= sse_thresh_) {      // jly_goicp.cpp:416
+				// single rank: global convergence.  sharded: this rank's frontier can no longer improve
+				if (parents.empty()) { queue_.pop(); cnt_.rot_pops++; pops++; converged_ = true; }
+				break;
+			}
+			queue_.pop();
+			cnt_.rot_pops++;
+			pops++;
+			parents.push_back(parent);
 		}
-		process_parent(parent);
+		if (parents.empty()) break;
+		process_parents(parents);
 		publish(false);
 	}
 	StepStatus st{};

@@ -21,7 +21,8 @@ struct Params {
 	int dt_layout = 1;            // 0 linear, 1 bricked 4x4x4
 	int device = -1;              // -1: current HIP device
 	int trans_batch = 16;         // translation nodes expanded per inner search per launch (1 = reference order)
-	int wide_children = 1;        // run the 8 rotation children's inner searches concurrently (0 = reference order)
+	int wide_children = 1;        // run the rotation children's inner searches concurrently (0 = reference order)
+	int rot_batch = 4;            // rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches)
 	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
 	int verbose = 0;
 	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
@@ -107,7 +108,7 @@ private:
 	struct InnerSearch;
 	void ensure_batch(size_t B, size_t K);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
-	void process_parent(const Node& parent);
+	void process_parents(const std::vector<Node>& parents);
 	void adopt(float err, const float R[9], const float t[3]);
 	float icp_from(float R[9], float t[3]);
 	void publish(bool finished);

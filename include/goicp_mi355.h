@@ -92,10 +92,11 @@ typedef struct goicp_params {
 	int32_t dt_layout;       /* 0 linear [z][y][x]; 1 bricked 4x4x4 (default) */
 	int32_t device;          /* HIP device ordinal, -1 = current */
 	int32_t trans_batch;     /* translation nodes expanded per search per launch; 1 = reference visit order */
-	int32_t wide_children;   /* 1: the 8 rotation children's inner searches run concurrently; 0 = reference order */
+	int32_t wide_children;   /* 1: the rotation children's ub and lb inner searches run in lock-step; 0 = reference order */
 	int32_t icp_max_iter;    /* reference 10000 (src/goicp/jly_icp3d.hpp:114) */
 	int32_t verbose;
 	int32_t morton_sort;     /* 1: source cloud kept in Morton order on the device */
+	int32_t rot_batch;       /* rotation nodes expanded per round when wide_children (default 4) */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);

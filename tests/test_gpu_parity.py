@@ -238,15 +238,24 @@ def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):
 # ----------------------------------------------------------------------------------------------
 # end to end (FastGoICP::run == GoICP::Register)
 # ----------------------------------------------------------------------------------------------
-def _e2e(pkg, tag, model, data, **params):
+def _e2e(pkg, tag, model, data, strict=True, **params):
+    """strict (reference visit order): R within 2e-3 rad, t within 2e-3, SSE within 2 %.
+    Widened search (speculative batches): Go-ICP's guarantee is the error, not the pose -- the early
+    exit (jly_goicp.cpp:527) accepts the first ICP optimum below SSEThresh, and a different visit order
+    can hand ICP a different start inside the same basin (bunny/10: a 0.02 rad neighbour with a LOWER
+    SSE).  So: SSE <= reference (+2 %), below SSEThresh, pose within 3e-2 rad / 1e-2."""
     g = golden("e2e_" + tag)
     eng = pkg.FastGoICP(model, data, g["mse_threshold"], **params)
     eng.run()
     assert eng.finished
     sse = eng.get_best_error()
-    assert rot_angle(eng.optR, np.array(g["R"])) <= 2e-3               # rad
-    assert np.linalg.norm(eng.optT - np.array(g["t"])) <= 2e-3
-    assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+    ang, dt = rot_angle(eng.optR, np.array(g["R"])), np.linalg.norm(eng.optT - np.array(g["t"]))
+    if strict:
+        assert ang <= 2e-3 and dt <= 2e-3
+        assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+    else:
+        assert ang <= 3e-2 and dt <= 1e-2
+        assert sse <= 1.02 * g["sse"]
     assert sse < g["sse_threshold"]
     return eng, g
 
@@ -259,7 +268,7 @@ def test_e2e_rand100_reference_order(pkg):
 
 
 def test_e2e_rand100_wide(pkg):
-    _e2e(pkg, "rand100", cloud("model_rand"), cloud("data_rand"))
+    _e2e(pkg, "rand100", cloud("model_rand"), cloud("data_rand"), strict=False)
 
 
 def test_e2e_bunny10_reference_order(pkg, bunny_model, bunny_data10):
@@ -270,16 +279,25 @@ def test_e2e_bunny10_reference_order(pkg, bunny_model, bunny_data10):
 
 
 def test_e2e_bunny10_wide(pkg, bunny_model, bunny_data10):
-    _e2e(pkg, "bunny10", bunny_model, bunny_data10)
+    _e2e(pkg, "bunny10", bunny_model, bunny_data10, strict=False)
 
 
 def test_e2e_bunny_full_wide(pkg, bunny_model, bunny_data, tmp_path):
     """BASELINE configs[1]: bunny_goicp, N = 30379, V = 300 (reference CPU: 502.7 s)."""
-    eng, g = _e2e(pkg, "bunny_full", bunny_model, bunny_data)
+    eng, g = _e2e(pkg, "bunny_full", bunny_model, bunny_data, strict=False)
     out = tmp_path / "output.toml"
     eng.write_output(out)
     txt = out.read_text()
     assert "rotation" in txt and "translation" in txt and "sse" in txt
+
+
+def test_e2e_bunny_full_reference_order(pkg, bunny_model, bunny_data):
+    """Full bunny in the reference visit order (8 cubes per launch): strict pose/SSE parity and node
+    counts against the reference's own run (378 rotation / 46 862 translation nodes)."""
+    eng, g = _e2e(pkg, "bunny_full", bunny_model, bunny_data, trans_batch=1, wide_children=0)
+    c = eng.counters
+    assert abs(c.rot_pops - g["rNodeCount"]) <= 0.02 * g["rNodeCount"]
+    assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"]
 
 
 def test_sharded_two_ranks_same_optimum(pkg, bunny_model, bunny_data10):
@@ -289,8 +307,8 @@ def test_sharded_two_ranks_same_optimum(pkg, bunny_model, bunny_data10):
     g = golden("e2e_bunny10")
     engines = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"]) for _ in range(2)]
     sse, R, t, stats = sharded.run_local_ranks(engines, rot_pops_per_step=4)
-    assert rot_angle(R, np.array(g["R"])) <= 2e-3 and np.linalg.norm(t - np.array(g["t"])) <= 2e-3
-    assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+    assert rot_angle(R, np.array(g["R"])) <= 3e-2 and np.linalg.norm(t - np.array(g["t"])) <= 1e-2
+    assert sse <= 1.02 * g["sse"] and sse < g["sse_threshold"]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -311,99 +311,104 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 }
 
 // ------------------------------------------------------------------------------------------------
-// (b) ICP: exact 1-NN in the flattened k-d tree.
-// The walk is a chain of dependent accesses, so latency per step and the NUMBER of steps decide
-// the speed, not bandwidth.  Measured on MI355X: a plain split-plane walk costs ~1000 leaf rounds
-// per wavefront for queries far from the surface (3.9 ms per pass at the identity pose).  Hence:
-//  (1) every node carries the tight bounding boxes of its two children (16-bit, conservatively
-//      quantised, 24 B/node): a subtree is entered only if its box is within the best distance;
-//  (2) the search starts from the upper bound (DT(q) + 2.5 voxel)^2 read from the distance
-//      transform the engine already holds, so even far queries go straight to the few leaves
-//      around their true neighbour;
-//  (3) the box records (<= 96 KB) are staged in LDS once per workgroup: a step costs LDS latency;
-//  (4) a leaf is two aligned 128-B lines of 16 float4 slots (padded with +inf), fetched with
-//      independent loads: one memory latency per leaf, no offset indirection;
-//  (5) the walk is stackless (heap indices; on the way up the parent's record is re-read from LDS
-//      and the visit order re-derived from the box distances, which depend on the query only) and
-//      re-converges the wavefront before every leaf scan, so a wave pays max-over-lanes (not
-//      sum-over-lanes) memory latencies.
-// Exactness: box lower bounds use the same monotone float accumulation as the point distances,
-// boxes are conservative, ties go to the lowest original index -> identical to brute force.
+// (b) ICP: exact 1-NN in the flattened k-d tree -- one WAVEFRONT per query, 64-ary.
+// Measured on MI355X, a per-lane walk of a binary tree is hopeless at this size: 30 k queries are
+// only 475 wavefronts, every step is a dependent, divergent access, and a wave is as slow as its
+// unluckiest lane (1.3 ms per pass, 3.9 ms for queries far from the surface).  So the tree the
+// host builds by median splits is flattened into a 64-ary hierarchy of tight bounding boxes --
+// branching factor = wave width:
+//   * a wavefront owns one query; lane l tests child box l of the current group (6 coalesced
+//     256-B loads for the 64 boxes), the candidates are a 64-bit ballot;
+//   * children are entered nearest-box-first, and only while their box is within the best
+//     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes and min-reduced
+//     with DPP shuffles; after every improvement the pending ballots are re-filtered;
+//   * the search starts from the upper bound (DT(q) + 2.5 voxel)^2 read from the distance
+//     transform the engine already holds, so queries far from the surface prune as well as
+//     near ones;
+//   * all control flow is wave-uniform: no divergence, no per-lane stack, no tail lanes.
+// Depth K = 2 covers 64*64*16 = 65 536 target points, K = 3 up to 4.2 M.
+// Exactness: box lower bounds use the same monotone float accumulation as the point distances and
+// the boxes are exact, ties go to the lowest original index -> identical to a brute-force scan.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsNodes = 4096;        // 96 KB of LDS: the whole tree up to M = 64 k target points, the top 12 levels beyond
-constexpr int kIcpThreads = 256;
+constexpr int kIcpThreads = 256;     // 4 wavefronts per workgroup
+constexpr int kIcpQueriesPerWave = 2;
 
-__device__ __forceinline__ void stage_nodes(const KdDesc& kd, uint2* lds)
-{
-	const int n = (kd.L < kLdsNodes ? kd.L : kLdsNodes) * 3;
-	for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = kd.boxes[i];
-	__syncthreads();
-}
+struct NnResult { float best; int idx; int slot; };
 
-// squared distance from q to the box {lo, hi} decoded from three packed words (x: lo|hi<<16, ...)
-__device__ __forceinline__ float box_lb(const KdDesc& kd, unsigned wx, unsigned wy, unsigned wz, float qx, float qy, float qz)
+__device__ __forceinline__ float child_box_lb(const float* __restrict__ g, int lane, float qx, float qy, float qz)
 {
-	const float lox = kd.root_lo[0] + (float)(wx & 0xffffu) * kd.step[0], hix = kd.root_lo[0] + (float)(wx >> 16) * kd.step[0];
-	const float loy = kd.root_lo[1] + (float)(wy & 0xffffu) * kd.step[1], hiy = kd.root_lo[1] + (float)(wy >> 16) * kd.step[1];
-	const float loz = kd.root_lo[2] + (float)(wz & 0xffffu) * kd.step[2], hiz = kd.root_lo[2] + (float)(wz >> 16) * kd.step[2];
+	// group record: lo_x[64] lo_y[64] lo_z[64] hi_x[64] hi_y[64] hi_z[64]
+	const float lox = g[lane], loy = g[64 + lane], loz = g[128 + lane];
+	const float hix = g[192 + lane], hiy = g[256 + lane], hiz = g[320 + lane];
 	const float ex = fmaxf(fmaxf(lox - qx, qx - hix), 0.f);
 	const float ey = fmaxf(fmaxf(loy - qy, qy - hiy), 0.f);
 	const float ez = fmaxf(fmaxf(loz - qz, qz - hiz), 0.f);
-	float d = ex * ex;         // same accumulation order as the point distance below
+	float d = ex * ex;         // same accumulation order as the point distance
 	d += ey * ey;
 	d += ez * ez;
-	return d;
+	return d;                  // +inf for an empty child (lo = +inf, hi = -inf)
 }
 
-template <bool kAllLds>
-__device__ __forceinline__ void kd_nearest(const KdDesc& kd, const uint2* lds, float qx, float qy, float qz, float bound,
-                                           float& best, int& bidx, int& bslot)
+// The candidate sets are small (a handful of lanes), so minima are taken with a scalar loop over the
+// set bits of a ballot (s_ff1 + v_readlane) instead of 64-lane shuffle ladders.
+__device__ __forceinline__ int nearest_pending(float lb, unsigned long long pending)
 {
-	const int L = kd.L;
-	best = bound; bidx = INT_MAX; bslot = 0;
-	int node = 1;
-	bool down = true, done = false;
-	while (__any(!done)) {
-		// ---- phase A: to the next leaf (or off the root); one branch-free step per iteration ----
-		while (!done && (!down || node < L)) {
-			const int at = down ? node : (node >> 1);
-			uint2 w0, w1, w2;
-			if (kAllLds || at < kLdsNodes) { w0 = lds[3 * at]; w1 = lds[3 * at + 1]; w2 = lds[3 * at + 2]; }
-			else { w0 = kd.boxes[3 * at]; w1 = kd.boxes[3 * at + 1]; w2 = kd.boxes[3 * at + 2]; }
-			const float lbl = box_lb(kd, w0.x, w0.y, w1.x, qx, qy, qz);      // left child 2*at
-			const float lbr = box_lb(kd, w1.y, w2.x, w2.y, qx, qy, qz);      // right child 2*at+1
-			const int first = 2 * at + (lbl <= lbr ? 0 : 1);
-			const float lb_first = fminf(lbl, lbr), lb_second = fmaxf(lbl, lbr);
-			if (down) {
-				if (lb_first <= best) node = first; else down = false;       // nothing closer below: turn around here
-			} else if (node == 1) {
-				done = true;                                                  // walked off the root
-			} else if (node == first && lb_second <= best) {
-				node = first ^ 1; down = true;                                // the sibling may hold a closer point
-			} else {
-				node = at;
-			}
-		}
-		// ---- phase B: scan the leaf ----
-		if (!done) {
-			const int base = (node - L) * kLeafSlots;
-			float4 p[kLeafSlots];
-#pragma unroll
-			for (int k = 0; k < kLeafSlots; k++) p[k] = kd.pts[base + k];
-#pragma unroll
-			for (int k = 0; k < kLeafSlots; k++) {
-				// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
-				const float d0 = qx - p[k].x, d1 = qy - p[k].y, d2 = qz - p[k].z;
-				float d = d0 * d0;
-				d += d1 * d1;
-				d += d2 * d2;
-				const int id = __float_as_int(p[k].w);
-				if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bslot = base + k; }
-			}
-			down = false;
-			if (node == 1) done = true;                                       // single-leaf tree
-		}
+	int best_c = -1;
+	float best_v = INFINITY;
+	while (pending) {
+		const int c = __ffsll((long long)pending) - 1;
+		pending &= pending - 1;
+		const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), c));
+		if (best_c < 0 || v < best_v) { best_v = v; best_c = c; }
 	}
+	return best_c;
+}
+
+__device__ __forceinline__ void scan_leaf(const KdDesc& kd, int leaf, int lane, float qx, float qy, float qz, NnResult& r)
+{
+	float d = INFINITY; int id = INT_MAX;
+	if (lane < kLeafSlots) {
+		const float4 p = kd.pts[leaf * kLeafSlots + lane];
+		// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
+		const float d0 = qx - p.x, d1 = qy - p.y, d2 = qz - p.z;
+		d = d0 * d0;
+		d += d1 * d1;
+		d += d2 * d2;
+		id = __float_as_int(p.w);
+	}
+	// lanes whose point beats the current best (ties -> lowest original index); usually none or one
+	unsigned long long better = __ballot(d < r.best || (d == r.best && id < r.idx));
+	while (better) {
+		const int c = __ffsll((long long)better) - 1;
+		better &= better - 1;
+		const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), c));
+		const int iv = __builtin_amdgcn_readlane(id, c);
+		if (dv < r.best || (dv == r.best && iv < r.idx)) { r.best = dv; r.idx = iv; r.slot = leaf * kLeafSlots + c; }
+	}
+}
+
+template <int K, int LVL>
+__device__ __forceinline__ void visit_group(const KdDesc& kd, int group, int lane, float qx, float qy, float qz, NnResult& r)
+{
+	const float lb = child_box_lb(kd.boxes[LVL] + (size_t)group * 384, lane, qx, qy, qz);
+	unsigned long long pending = __ballot(lb <= r.best);
+	while (pending) {
+		const int c = nearest_pending(lb, pending);                      // nearest pending child
+		pending &= ~(1ull << c);
+		const int child = group * 64 + c;
+		if (LVL == K - 1) scan_leaf(kd, child, lane, qx, qy, qz, r);
+		else visit_group<K, (LVL + 1 < K ? LVL + 1 : LVL)>(kd, child, lane, qx, qy, qz, r);
+		pending &= __ballot(lb <= r.best);                              // re-filter with the improved bound
+	}
+}
+
+// exact 1-NN of one query by the whole wavefront (all lanes hold the same q and get the same result)
+template <int K>
+__device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, int lane, float qx, float qy, float qz, float bound)
+{
+	NnResult r{bound, INT_MAX, 0};
+	visit_group<K, 0>(kd, 0, lane, qx, qy, qz, r);
+	return r;
 }
 
 // upper bound on the NN distance from the distance transform: DT(q) is exact between voxel centres,
@@ -415,49 +420,49 @@ __device__ __forceinline__ float nn_upper_bound(const DtDesc& dt, float qx, floa
 	return d * d;
 }
 
-template <bool kAllLds, int LAYOUT>
+template <int K, int LAYOUT>
 __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                                float* __restrict__ partials)
 {
-	__shared__ uint2 lds_nodes[kLdsNodes * 3];
 	__shared__ float red[kIcpThreads / 64][kIcpAcc];
 	if (st->converged) return;                                          // loop already finished: queued launches drain
-	stage_nodes(kd, lds_nodes);
-	const int i = blockIdx.x * kIcpThreads + threadIdx.x;
-	const bool valid = i < N;
-	const float4 p = src[valid ? i : N - 1];
-	// jly_icp3d.hpp:222-224, left-to-right float sums
-	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-	float d2; int id, slot;
-	kd_nearest<kAllLds>(kd, lds_nodes, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz), d2, id, slot);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int w = blockIdx.x * (kIcpThreads / 64) + wave;               // global wavefront index
 	float acc[kIcpAcc];
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
-	if (valid) {
-		const float4 m = kd.pts[slot];
+	for (int j = 0; j < kIcpQueriesPerWave; j++) {
+		const int i = w * kIcpQueriesPerWave + j;
+		if (i >= N) break;                                               // wave-uniform
+		const float4 p = src[i];
+		// jly_icp3d.hpp:222-224, left-to-right float sums
+		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+		const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
+		const float4 m = kd.pts[r.slot];
 		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
 		const float bx = m.x - st->cm[0], by = m.y - st->cm[1], bz = m.z - st->cm[2];
-		acc[0] = ax; acc[1] = ay; acc[2] = az;
-		acc[3] = bx; acc[4] = by; acc[5] = bz;
-		acc[6] = ax * bx; acc[7] = ax * by; acc[8] = ax * bz;
-		acc[9] = ay * bx; acc[10] = ay * by; acc[11] = ay * bz;
-		acc[12] = az * bx; acc[13] = az * by; acc[14] = az * bz;
-		acc[15] = d2;
+		acc[0] += ax; acc[1] += ay; acc[2] += az;
+		acc[3] += bx; acc[4] += by; acc[5] += bz;
+		acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
+		acc[9] += ay * bx; acc[10] += ay * by; acc[11] += ay * bz;
+		acc[12] += az * bx; acc[13] += az * by; acc[14] += az * bz;
+		acc[15] += r.best;
 	}
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// every lane of a wave holds the same sums: lane k publishes component k
+	if (lane < kIcpAcc) {
+		float v = 0.f;
 #pragma unroll
-	for (int k = 0; k < kIcpAcc; k++) {
-		const float s = wave_sum(acc[k]);
-		if (lane == 0) red[wave][k] = s;
+		for (int k = 0; k < kIcpAcc; k++) v = lane == k ? acc[k] : v;
+		red[wave][lane] = v;
 	}
 	__syncthreads();
 	if (threadIdx.x < kIcpAcc) {
 		float s = red[0][threadIdx.x];
 #pragma unroll
-		for (int w = 1; w < kIcpThreads / 64; w++) s += red[w][threadIdx.x];
+		for (int x = 1; x < kIcpThreads / 64; x++) s += red[x][threadIdx.x];
 		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = s;
 	}
 }
@@ -533,9 +538,9 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 // SVD, R_ / t_, compose.  The pose lives in device memory, so the host can queue several iterations
 // back-to-back without a round trip.
 __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
-                                                                     IcpState* __restrict__ st)
+                                                                     IcpState* __restrict__ state)
 {
-	if (st->converged) return;
+	if (state->converged) return;
 	__shared__ double sums[kIcpAcc];
 	const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	double s = 0.0;
@@ -544,26 +549,28 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 	if (lane == 0) sums[k] = s;
 	__syncthreads();
 	if (threadIdx.x != 0) return;
+	IcpState st = *state;            // one burst of loads; the serial part below runs on registers
 	const float err_new = (float)sums[15];
-	st->err_new = err_new;
-	st->passes += 1;
-	if (st->frozen) return;                                                  // timing / scoring only
-	if (st->err > 0.f && st->err - err_new < st->err_diff_n) { st->converged = 1; return; }   // jly_icp3d.hpp:255
-	st->err = err_new;
-	const double nn = (double)st->n;
+	st.err_new = err_new;
+	st.passes += 1;
+	if (st.frozen) { state->err_new = err_new; state->passes = st.passes; return; }   // timing / scoring only
+	if (st.err > 0.f && st.err - err_new < st.err_diff_n) {                  // jly_icp3d.hpp:255
+		state->err_new = err_new; state->passes = st.passes; state->converged = 1;
+		return;
+	}
+	st.err = err_new;
+	const double nn = (double)st.n;
 	double alpha[3], beta[3];
-	float mu_d[3], mu_m[3];
 	for (int a = 0; a < 3; a++) {
-		const double sum_q = sums[a] + nn * (double)st->cq[a];
-		const double sum_m = sums[3 + a] + nn * (double)st->cm[a];
+		const double sum_q = sums[a] + nn * (double)st.cq[a];
+		const double sum_m = sums[3 + a] + nn * (double)st.cm[a];
 		// jly_icp3d.hpp:244-263: the reference accumulates on top of the previous means and divides by n
-		const double carry_d = st->carry_means ? (double)st->mu_d[a] : 0.0;
-		const double carry_m = st->carry_means ? (double)st->mu_m[a] : 0.0;
-		mu_d[a] = (float)((carry_d + sum_q) / nn);
-		mu_m[a] = (float)((carry_m + sum_m) / nn);
-		st->mu_d[a] = mu_d[a]; st->mu_m[a] = mu_m[a];
-		alpha[a] = (double)mu_d[a] - (double)st->cq[a];
-		beta[a] = (double)mu_m[a] - (double)st->cm[a];
+		const double carry_d = st.carry_means ? (double)st.mu_d[a] : 0.0;
+		const double carry_m = st.carry_means ? (double)st.mu_m[a] : 0.0;
+		st.mu_d[a] = (float)((carry_d + sum_q) / nn);
+		st.mu_m[a] = (float)((carry_m + sum_m) / nn);
+		alpha[a] = (double)st.mu_d[a] - (double)st.cq[a];
+		beta[a] = (double)st.mu_m[a] - (double)st.cm[a];
 	}
 	double H[9];
 	for (int i = 0; i < 3; i++)
@@ -575,39 +582,49 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 	kabsch_rotation_dev(H, R_);
 	for (int i = 0; i < 3; i++) {
 		float acc = 0.f;
-		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * mu_d[a];
-		t_[i] = mu_m[i] - acc;                                                // t_ = mu_m - R_ mu_d
+		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.mu_d[a];
+		t_[i] = st.mu_m[i] - acc;                                             // t_ = mu_m - R_ mu_d
 	}
 	for (int i = 0; i < 3; i++) {
 		for (int j = 0; j < 3; j++) {
 			float acc = 0.f;
-			for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st->R[3 * a + j];
+			for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.R[3 * a + j];
 			Rn[3 * i + j] = acc;                                              // R <- R_ R
 		}
 		float acc = 0.f;
-		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st->t[a];
+		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.t[a];
 		tn[i] = acc + t_[i];                                                  // t <- R_ t + t_
 	}
-	for (int i = 0; i < 9; i++) st->R[i] = Rn[i];
+	for (int i = 0; i < 9; i++) st.R[i] = Rn[i];
 	for (int i = 0; i < 3; i++) {
-		st->t[i] = tn[i];
-		st->cq[i] = Rn[3 * i] * st->src_centroid[0] + Rn[3 * i + 1] * st->src_centroid[1] + Rn[3 * i + 2] * st->src_centroid[2] + tn[i];
+		st.t[i] = tn[i];
+		st.cq[i] = Rn[3 * i] * st.src_centroid[0] + Rn[3 * i + 1] * st.src_centroid[1] + Rn[3 * i + 2] * st.src_centroid[2] + tn[i];
 	}
-	st->iters += 1;
+	st.iters += 1;
+	*state = st;
 }
 
-int icp_blocks(int N) { return (N + kIcpThreads - 1) / kIcpThreads; }
+int icp_blocks(int N)
+{
+	const int per_block = (kIcpThreads / 64) * kIcpQueriesPerWave;
+	return (N + per_block - 1) / per_block;
+}
+
+template <int K>
+static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, hipStream_t stream)
+{
+	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
+	if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	else hipLaunchKernelGGL((icp_pass_kernel<K, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+}
 
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
                                 hipStream_t stream)
 {
-	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
-	const bool all = kd.L <= kLdsNodes;
-	if (all && dt.layout) hipLaunchKernelGGL((icp_pass_kernel<true, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
-	else if (all) hipLaunchKernelGGL((icp_pass_kernel<true, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
-	else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<false, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
-	else hipLaunchKernelGGL((icp_pass_kernel<false, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
-	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, (int)grid.x, st);
+	if (kd.K == 1) launch_pass_k<1>(src, N, st, kd, dt, partials, stream);
+	else if (kd.K == 2) launch_pass_k<2>(src, N, st, kd, dt, partials, stream);
+	else launch_pass_k<3>(src, N, st, kd, dt, partials, stream);
+	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, icp_blocks(N), st);
 	return hipGetLastError();
 }
 
@@ -629,29 +646,32 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 	return hipGetLastError();
 }
 
-template <bool kAllLds, int LAYOUT>
+template <int K, int LAYOUT>
 __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, DtDesc dt,
                                                                int32_t* __restrict__ idx, float* __restrict__ d2)
 {
-	__shared__ uint2 lds_nodes[kLdsNodes * 3];
-	stage_nodes(kd, lds_nodes);
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	const int j = i < n ? i : n - 1;
-	const float qx = q[3 * j], qy = q[3 * j + 1], qz = q[3 * j + 2];
-	float best; int id, slot;
-	kd_nearest<kAllLds>(kd, lds_nodes, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz), best, id, slot);
-	if (i < n) { idx[i] = id; d2[i] = best; }
+	const int lane = threadIdx.x & 63;
+	const int i = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);   // one wavefront per query
+	if (i >= n) return;
+	const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+	const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
+	if (lane == 0) { idx[i] = r.idx; d2[i] = r.best; }
+}
+
+template <int K>
+static void launch_nn_k(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
+{
+	const dim3 grid((n + kIcpThreads / 64 - 1) / (kIcpThreads / 64)), block(kIcpThreads);
+	if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<K, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
+	else hipLaunchKernelGGL((nn_query_kernel<K, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 }
 
 hipError_t launch_nn_query(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
 {
 	if (n <= 0) return hipSuccess;
-	const dim3 grid((n + kIcpThreads - 1) / kIcpThreads), block(kIcpThreads);
-	const bool all = kd.L <= kLdsNodes;
-	if (all && dt.layout) hipLaunchKernelGGL((nn_query_kernel<true, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
-	else if (all) hipLaunchKernelGGL((nn_query_kernel<true, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
-	else if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<false, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
-	else hipLaunchKernelGGL((nn_query_kernel<false, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
+	if (kd.K == 1) launch_nn_k<1>(q, n, kd, dt, idx, d2, stream);
+	else if (kd.K == 2) launch_nn_k<2>(q, n, kd, dt, idx, d2, stream);
+	else launch_nn_k<3>(q, n, kd, dt, idx, d2, stream);
 	return hipGetLastError();
 }
 

@@ -34,19 +34,20 @@ static_assert(sizeof(CubeRec) == 24, "CubeRec layout");
 
 struct Rot9 { float r[9]; };   // row-major
 
-// Flattened k-d tree over the target cloud: implicit, left-balanced, heap indexed --
-// root = 1, children of n are 2n and 2n+1, leaves are nodes [L, 2L).  Internal node n carries the
-// tight bounding boxes of its two children, 16-bit quantised against the root box with conservative
-// rounding: 3 x uint2 = {Lx, Ly | Lz, Rx | Ry, Rz}, each word lo | hi << 16.  Leaf l owns the
-// kLeafSlots consecutive float4 slots pts[kLeafSlots*l ...] (aligned 128-B lines); unused slots hold
-// +inf coordinates with index INT_MAX, so they never win.
+// Flattened k-d tree over the target cloud.  The host builds a balanced binary k-d
+// tree by median splits and flattens it into a 64-ary hierarchy of tight bounding boxes with K
+// levels (branching factor = wavefront width): group g of level l holds its 64 children's boxes as
+// six runs of 64 floats {lo_x, lo_y, lo_z, hi_x, hi_y, hi_z} (384 floats); level l has 64^l groups;
+// the children of group g are groups 64g .. 64g+63 of level l+1, or, on the last level, leaves.
+// Leaf f owns the kLeafSlots consecutive float4 slots pts[kLeafSlots*f ...] (one aligned 256-B block);
+// unused slots hold +inf coordinates with index INT_MAX, empty children have inverted infinite boxes.
 constexpr int kLeafSlots = 16;
+constexpr int kMaxLevels = 3;
 struct KdDesc {
-	const uint2* boxes;       // [3*L]; entries of node 0 unused
-	const float4* pts;        // [kLeafSlots*L]  leaf order; .w = original index (int bits)
-	int L;                    // number of leaves (power of two)
+	const float* boxes[kMaxLevels];  // boxes[l]: 64^l groups x 384 floats
+	const float4* pts;               // [kLeafSlots * 64^K]  leaf order; .w = original index (int bits)
+	int K;                           // levels: 64^K leaves
 	int M;
-	float root_lo[3], step[3]; // box coordinate = root_lo + code * step
 };
 
 struct Pose { float R[9]; float t[3]; };

@@ -197,12 +197,15 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	{
 		KdHost kh;
 		build_kdtree(target, (int)M_, kLeafSlots, &kh);
-		HIPCHK(hipMalloc(&d_kd_boxes_, sizeof(uint2) * kh.boxes.size()));
+		for (int l = 0; l < kh.K; l++) {
+			HIPCHK(hipMalloc(&d_kd_boxes_[l], sizeof(float) * kh.boxes[l].size()));
+			HIPCHK(hipMemcpy(d_kd_boxes_[l], kh.boxes[l].data(), sizeof(float) * kh.boxes[l].size(), hipMemcpyHostToDevice));
+			kd_.boxes[l] = d_kd_boxes_[l];
+		}
+		for (int l = kh.K; l < kMaxLevels; l++) kd_.boxes[l] = nullptr;
 		HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
-		HIPCHK(hipMemcpy(d_kd_boxes_, kh.boxes.data(), sizeof(uint2) * kh.boxes.size(), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
-		kd_.boxes = d_kd_boxes_; kd_.pts = d_kd_pts_; kd_.L = kh.L; kd_.M = (int)M_;
-		for (int k = 0; k < 3; k++) { kd_.root_lo[k] = kh.root_lo[k]; kd_.step[k] = kh.step[k]; }
+		kd_.pts = d_kd_pts_; kd_.K = kh.K; kd_.M = (int)M_;
 	}
 	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)icp_blocks((int)N_) * kIcpAcc));
 	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
@@ -219,7 +222,8 @@ Engine::~Engine()
 {
 	hipStreamSynchronize(stream_);
 	hipFree(d_src_); hipFree(d_dt_);
-	hipFree(d_kd_boxes_); hipFree(d_kd_pts_);
+	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
+	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
 	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_);

@@ -130,7 +130,7 @@ private:
 	float* d_dt_ = nullptr;
 	// k-d tree
 	KdDesc kd_{};
-	uint2* d_kd_boxes_ = nullptr; float4* d_kd_pts_ = nullptr;
+	float* d_kd_boxes_[kMaxLevels] = {nullptr, nullptr, nullptr}; float4* d_kd_pts_ = nullptr;
 	// bounds staging
 	size_t cap_cubes_ = 0, cap_rots_ = 0, cap_scratch_ = 0;
 	CubeRec* d_cubes_ = nullptr; CubeRec* h_cubes_ = nullptr;
@@ -158,8 +158,9 @@ private:
 
 // ---- host utilities (config_io.cpp, kdtree.cpp) ----
 struct KdHost {
-	std::vector<uint2> boxes; std::vector<float4> pts; int L = 1;   // boxes: 3 words per node; pts: kLeafSlots slots per leaf
-	float root_lo[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+	std::vector<std::vector<float>> boxes;   // per level: 64^l groups x 384 floats
+	std::vector<float4> pts;                 // kLeafSlots slots per leaf
+	int K = 1, L = 64;
 };
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
 void rodrigues(float v1, float v2, float v3, float R[9]);   // jly_goicp.cpp:449-467

@@ -4,26 +4,25 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <stdexcept>
 
 #include "engine.hpp"
 
 namespace goicp {
 
-// Heap-indexed tree: node n in [1, L) is internal with children 2n, 2n+1; nodes [L, 2L) are the
-// leaves.  Median split by count along the widest extent of the node's points, so every leaf holds
-// <= leaf_max points and no child pointers are needed (the kernel derives parent/sibling indices
-// arithmetically, which is what makes the stackless walk possible).  Every internal node stores the
-// tight boxes of its two children, quantised to 16 bits so that the decoded box (the same float
-// expression the kernel evaluates) always CONTAINS the true box.
+// Balanced binary k-d tree by median splits along the widest extent (depth 6K, 64^K leaves of
+// <= kLeafSlots points), flattened into K levels of 64-ary box groups: a level-l group is the
+// subtree rooted at binary depth 6l, its 64 children are the nodes 6 binary levels below.
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 {
-	int D = 0;
-	while (((M + (1 << D) - 1) >> D) > leaf_max) D++;
-	const int L = 1 << D;
-	out->L = L;
+	int K = 1;
+	while (K < kMaxLevels && (long long)leaf_max * (1LL << (6 * K)) < (long long)M) K++;
+	if ((long long)leaf_max * (1LL << (6 * K)) < (long long)M) throw std::invalid_argument("goicp: target cloud too large for the k-d tree");
+	const int D = 6 * K, L = 1 << D;
+	out->K = K; out->L = L;
 	std::vector<int> idx(M);
 	std::iota(idx.begin(), idx.end(), 0);
-	std::vector<int> lo(2 * L + 1, 0), hi(2 * L + 1, 0);
+	std::vector<int> lo(2 * (size_t)L, 0), hi(2 * (size_t)L, 0);   // heap order: node n -> children 2n, 2n+1
 	lo[1] = 0; hi[1] = M;
 	for (int n = 1; n < L; n++) {
 		const int a = lo[n], b = hi[n];
@@ -44,10 +43,10 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 				return fp < fq || (fp == fq && p < q);
 			});
 		}
-		lo[2 * n] = a; hi[2 * n] = mid;
-		lo[2 * n + 1] = mid; hi[2 * n + 1] = b;
+		lo[2 * (size_t)n] = a; hi[2 * (size_t)n] = mid;
+		lo[2 * (size_t)n + 1] = mid; hi[2 * (size_t)n + 1] = b;
 	}
-	// fixed-size leaves: kLeafSlots float4 slots per leaf (aligned 128-B lines), padded with +inf points
+	// leaves: node L + f, left to right
 	float pad_w;
 	const int pad_id = INT32_MAX;
 	std::memcpy(&pad_w, &pad_id, sizeof(float));
@@ -55,49 +54,35 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 	struct Box { float lo[3], hi[3]; };
 	std::vector<Box> box(2 * (size_t)L);
 	for (auto& bx : box) for (int k = 0; k < 3; k++) { bx.lo[k] = INFINITY; bx.hi[k] = -INFINITY; }
-	for (int leaf = 0; leaf < L; leaf++) {
-		const int a = lo[L + leaf], b = hi[L + leaf];
+	for (int f = 0; f < L; f++) {
+		const int a = lo[(size_t)L + f], b = hi[(size_t)L + f];
 		for (int i = a; i < b; i++) {
 			const int id = idx[i];
 			float w;
 			std::memcpy(&w, &id, sizeof(float));
-			out->pts[(size_t)leaf * kLeafSlots + (i - a)] = make_float4(xyz[3 * id], xyz[3 * id + 1], xyz[3 * id + 2], w);
+			out->pts[(size_t)f * kLeafSlots + (i - a)] = make_float4(xyz[3 * id], xyz[3 * id + 1], xyz[3 * id + 2], w);
 			for (int k = 0; k < 3; k++) {
-				box[L + leaf].lo[k] = std::min(box[L + leaf].lo[k], xyz[3 * id + k]);
-				box[L + leaf].hi[k] = std::max(box[L + leaf].hi[k], xyz[3 * id + k]);
+				box[(size_t)L + f].lo[k] = std::min(box[(size_t)L + f].lo[k], xyz[3 * id + k]);
+				box[(size_t)L + f].hi[k] = std::max(box[(size_t)L + f].hi[k], xyz[3 * id + k]);
 			}
 		}
 	}
 	for (int n = L - 1; n >= 1; n--)
 		for (int k = 0; k < 3; k++) {
-			box[n].lo[k] = std::min(box[2 * n].lo[k], box[2 * n + 1].lo[k]);
-			box[n].hi[k] = std::max(box[2 * n].hi[k], box[2 * n + 1].hi[k]);
+			box[n].lo[k] = std::min(box[2 * (size_t)n].lo[k], box[2 * (size_t)n + 1].lo[k]);
+			box[n].hi[k] = std::max(box[2 * (size_t)n].hi[k], box[2 * (size_t)n + 1].hi[k]);
 		}
-	for (int k = 0; k < 3; k++) {
-		out->root_lo[k] = box[1].lo[k];
-		float ext = box[1].hi[k] - box[1].lo[k];
-		out->step[k] = ext > 0.f ? ext / 65535.0f : 1e-30f;
-	}
-	// the decode expression of the kernel (device.hip box_lb), float, not contracted
-	auto decode = [&](int k, unsigned code) { return out->root_lo[k] + (float)code * out->step[k]; };
-	for (int k = 0; k < 3; k++)
-		while (decode(k, 65535u) < box[1].hi[k]) out->step[k] *= 1.000001f;   // the top code must reach the root's upper face
-	auto quant = [&](const Box& bx, int k) -> unsigned {
-		if (!(bx.lo[k] <= bx.hi[k])) return 0xffffu | (0u << 16);            // empty child: inverted box, never entered
-		long cl = (long)std::floor((double)(bx.lo[k] - out->root_lo[k]) / (double)out->step[k]);
-		long ch = (long)std::ceil((double)(bx.hi[k] - out->root_lo[k]) / (double)out->step[k]);
-		cl = std::min(65535L, std::max(0L, cl));
-		ch = std::min(65535L, std::max(0L, ch));
-		while (cl > 0 && decode(k, (unsigned)cl) > bx.lo[k]) cl--;            // conservative under the kernel's rounding
-		while (ch < 65535 && decode(k, (unsigned)ch) < bx.hi[k]) ch++;
-		return (unsigned)cl | ((unsigned)ch << 16);
-	};
-	out->boxes.assign((size_t)L * 3, make_uint2(0xffffu, 0xffffu));
-	for (int n = 1; n < L; n++) {
-		const Box &l = box[2 * n], &r = box[2 * n + 1];
-		out->boxes[3 * (size_t)n] = make_uint2(quant(l, 0), quant(l, 1));
-		out->boxes[3 * (size_t)n + 1] = make_uint2(quant(l, 2), quant(r, 0));
-		out->boxes[3 * (size_t)n + 2] = make_uint2(quant(r, 1), quant(r, 2));
+	// level l: groups = binary nodes at depth 6l (heap index 2^(6l) + g), children = nodes at depth 6(l+1)
+	out->boxes.assign(K, std::vector<float>());
+	for (int l = 0; l < K; l++) {
+		const size_t groups = (size_t)1 << (6 * l);
+		out->boxes[l].assign(groups * 384, 0.f);
+		for (size_t g = 0; g < groups; g++)
+			for (int c = 0; c < 64; c++) {
+				const Box& bx = box[((size_t)1 << (6 * (l + 1))) + g * 64 + c];
+				float* rec = &out->boxes[l][g * 384];
+				for (int k = 0; k < 3; k++) { rec[64 * k + c] = bx.lo[k]; rec[192 + 64 * k + c] = bx.hi[k]; }
+			}
 	}
 }
 

@@ -25,5 +25,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ms = C.c_float()
         B.check(reg._lib.goicp_time_icp_pass(reg.handle, fp(R), fp(t), 20, C.byref(ms)))
         print("pose=%s: %.1f us per pass (kernel + finalize)" % (name, 1e3 * ms.value), flush=True)
+    import time
+    icp = pkg.IterativeClosestPoint3D(reg, 400, -1e30)
+    icp.run()
+    t0 = time.perf_counter(); icp = pkg.IterativeClosestPoint3D(reg, 400, -1e30); icp.run(); el = time.perf_counter() - t0
+    print("full loop: %.1f us per iteration (400 forced iterations from identity)" % (1e6 * el / 400), flush=True)
 else:
     subprocess.run([sys.executable, __file__, "child"])

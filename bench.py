@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--dt-size", type=int, default=300, help="tuning only: the BASELINE workload is 300")
     ap.add_argument("--morton", type=int, default=1, help="tuning only")
     ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
+                    help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL; one GPU per rank) | gloo (rehearsal: all ranks on GPU 0)")
     args = ap.parse_args()
 
     import torch
@@ -109,19 +112,33 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.backend == "gloo":
+        local_rank = 0                       # rehearsal of the N>1 path on a single GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from __graft_entry__ import _pkg
     pkg = _pkg()
     pkg.load_library()
     from cuda_go_icp_amd import binding as B
-    g = os.path.join(ROOT, "tests", "golden")
-    model = np.fromfile(os.path.join(g, "model_bunny.f32"), dtype="<f4").reshape(-1, 3)
-    data = np.fromfile(os.path.join(g, "data_bunny.f32"), dtype="<f4").reshape(-1, 3)
+    if args.workload == "bunny":
+        g = os.path.join(ROOT, "tests", "golden")
+        model = np.fromfile(os.path.join(g, "model_bunny.f32"), dtype="<f4").reshape(-1, 3)
+        data = np.fromfile(os.path.join(g, "data_bunny.f32"), dtype="<f4").reshape(-1, 3)
+        wname = "bunny_goicp.toml (BASELINE configs[1])"
+    else:
+        from cuda_go_icp_amd import synth
+        cfg = synth.S1 if args.workload == "s1" else synth.S2
+        model, data, _, _ = synth.make_pair(seed=cfg["seed"], M=cfg["M"], N=cfg["N"])
+        if args.dt_size == 300:
+            args.dt_size = cfg["V"]
+        wname = "synthetic %s (SURVEY 8d)" % args.workload.upper()
     N, M, V = len(data), len(model), args.dt_size
 
     reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, morton_sort=args.morton)
@@ -167,8 +184,17 @@ def main():
         B.check(lib.goicp_time_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), 10, C.byref(ms)))
         alg_bytes = (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N      # 16N ub pass, 20N lb pass
         achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+        # HBM-side traffic of the same launch: PMC counters cannot be read from inside this process; they
+        # were collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and
+        # WRITE_SIZE, gfx950 x2 correction on FETCH_SIZE) and are committed under profiles/
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_bounds.json")
+        if args.workload == "bunny" and args.dt_size == 300 and Bc == 65536 and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_b_pmc_bounds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; fabric-side of L2, includes Infinity-Cache hits)"
         roofline = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
         # ---- ICP iterations/s ----
@@ -198,7 +224,9 @@ def main():
             e2e = {"register_s": round(wall, 4), "sse": float(r.best_sse), "cube_bounds": int(r.counters.cubes),
                    "cube_bounds_per_s": round(r.counters.cubes / wall, 1), "rot_pops": int(r.counters.rot_pops),
                    "trans_pops": int(r.counters.trans_pops), "icp_iters": int(r.counters.icp_iters),
-                   "dt_build_ms": round(r.dt_build_ms, 2), "reference_cpu_register_s": 502.7, "reference_sse": 4.57226}
+                   "dt_build_ms": round(r.dt_build_ms, 2)}
+            if args.workload == "bunny":
+                e2e.update({"reference_cpu_register_s": 502.7, "reference_sse": 4.57226})
         cpu = None
         if not args.no_cpu:
             c = cpu_baseline(reg, model, data)
@@ -209,8 +237,8 @@ def main():
         out = {"metric": "bnb_cube_bounds_per_s", "value": round(value, 1), "unit": "cube-bounds/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-               "data": "Stanford-bunny clouds named by the reference's bunny_goicp.toml (committed fixture) + synthetic cube batch",
-               "config": {"workload": "bunny_goicp.toml (BASELINE configs[1]): N=%d source, M=%d target, DT %d^3, subsample 1.0" % (N, M, V),
+               "data": ("Stanford-bunny clouds named by the reference's bunny_goicp.toml (committed fixture)" if args.workload == "bunny" else "synthetic clouds (cuda-go-icp_amd/synth.py)") + " + synthetic cube batch",
+               "config": {"workload": "%s: N=%d source, M=%d target, DT %d^3, subsample 1.0" % (wname, N, M, V),
                           "cubes_per_step_per_gpu": Bc, "lb_pass_fraction": n_lb / Bc, "rotations_per_step": 8,
                           "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) best ub" if world > 1 else "local min"},
                "roofline": roofline, "cpu_baseline": cpu, "icp": icp, "e2e": e2e}

@@ -472,8 +472,8 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 {
 	double B[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, U[9], W[3];
 	for (int i = 0; i < 9; i++) B[i] = H[i];
-	for (int sweep = 0; sweep < 64; sweep++) {
-		double off = 0;
+	for (int sweep = 0; sweep < 32; sweep++) {
+		bool rotated = false;
 		for (int p = 0; p < 2; p++)
 			for (int q = p + 1; q < 3; q++) {
 				double app = 0, aqq = 0, apq = 0;
@@ -482,8 +482,9 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 					aqq += B[3 * i + q] * B[3 * i + q];
 					apq += B[3 * i + p] * B[3 * i + q];
 				}
-				off += apq * apq;
-				if (apq == 0.0 || fabs(apq) <= 1e-17 * sqrt(app * aqq)) continue;
+				// columns orthogonal to 1e-14 relative: the rotation is returned in float (6e-8)
+				if (apq == 0.0 || apq * apq <= 1e-28 * (app * aqq)) continue;
+				rotated = true;
 				const double zeta = (aqq - app) / (2 * apq);
 				const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
 				const double cs = 1 / sqrt(1 + tn * tn), sn = cs * tn;
@@ -496,7 +497,7 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 					V[3 * i + q] = sn * vp + cs * vq;
 				}
 			}
-		if (off < 1e-60) break;
+		if (!rotated) break;
 	}
 	for (int j = 0; j < 3; j++) {
 		const double n = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
@@ -541,12 +542,25 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
                                                                      IcpState* __restrict__ state)
 {
 	if (state->converged) return;
+	__shared__ double stream[64][kIcpAcc];
 	__shared__ double sums[kIcpAcc];
-	const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	double s = 0.0;
-	for (int b = lane; b < nblocks; b += 64) s += (double)partials[(size_t)b * kIcpAcc + k];
-	s = wave_sum_d(s);
-	if (lane == 0) sums[k] = s;
+	// 64 row streams x 16 components, 4 independent accumulators per thread (loads stay in flight),
+	// then fixed-order sums: deterministic
+	const int k = threadIdx.x & (kIcpAcc - 1), r = threadIdx.x >> 4;
+	double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+	for (int b = r; b < nblocks; b += 256) {
+		a0 += (double)partials[(size_t)b * kIcpAcc + k];
+		if (b + 64 < nblocks) a1 += (double)partials[(size_t)(b + 64) * kIcpAcc + k];
+		if (b + 128 < nblocks) a2 += (double)partials[(size_t)(b + 128) * kIcpAcc + k];
+		if (b + 192 < nblocks) a3 += (double)partials[(size_t)(b + 192) * kIcpAcc + k];
+	}
+	stream[r][k] = (a0 + a1) + (a2 + a3);
+	__syncthreads();
+	if (threadIdx.x < kIcpAcc) {
+		double s = 0.0;
+		for (int i = 0; i < 64; i++) s += stream[i][threadIdx.x];
+		sums[threadIdx.x] = s;
+	}
 	__syncthreads();
 	if (threadIdx.x != 0) return;
 	IcpState st = *state;            // one burst of loads; the serial part below runs on registers

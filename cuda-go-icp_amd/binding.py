@@ -86,6 +86,7 @@ SYMBOLS = {
     "goicp_cancel": (C.c_int, [_vp]),
     "goicp_poll": (C.c_int, [_vp, C.POINTER(CResult)]),
     "goicp_result_write_toml": (C.c_int, [_vp, C.c_char_p]),
+    "goicp_result_write_ply": (C.c_int, [_vp, C.c_char_p]),
     "goicp_transform_source": (C.c_int, [_vp, _fp, _fp, _fp]),
     "goicp_set_shard": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "goicp_register_begin": (C.c_int, [_vp]),

@@ -66,6 +66,7 @@ int main(int argc, char** argv)
 		for (int i = 0; i < 3; i++) std::printf("%12.7f %12.7f %12.7f\n", R[3 * i], R[3 * i + 1], R[3 * i + 2]);
 		std::printf("Optimal Translation Vector:\n%12.7f\n%12.7f\n%12.7f\n", t[0], t[1], t[2]);
 		if (!config.io.output.empty()) engine.write_output(config.io.output);
+		if (!config.io.visualization.empty()) engine.write_visualization(config.io.visualization);
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "error: %s\n", e.what());
 		return 1;

@@ -361,6 +361,25 @@ void load_cloud(const std::string& path, float subsample, float resize, uint64_t
 	else throw IoError("Unsupported file extension: " + ext);
 }
 
+void write_viz_ply(const std::string& path, const float* target, size_t nt, const float* source, size_t ns)
+{
+	FILE* f = std::fopen(path.c_str(), "wb");
+	if (!f) throw IoError("cannot write " + path);
+	std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment goicp-mi355: target (grey) + registered source (red)\n"
+	                "element vertex %zu\nproperty float x\nproperty float y\nproperty float z\n"
+	                "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", nt + ns);
+	auto put = [&](const float* p, size_t n, unsigned char r, unsigned char g, unsigned char b) {
+		for (size_t i = 0; i < n; i++) {
+			std::fwrite(p + 3 * i, sizeof(float), 3, f);
+			const unsigned char c[3] = {r, g, b};
+			std::fwrite(c, 1, 3, f);
+		}
+	};
+	put(target, nt, 160, 160, 160);
+	put(source, ns, 220, 40, 40);
+	std::fclose(f);
+}
+
 void write_result_toml(const std::string& path, const Result& r, size_t n_source, size_t n_target, float sse_threshold)
 {
 	FILE* f = std::fopen(path.c_str(), "w");

@@ -84,6 +84,7 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	HIPCHK(hipEventCreate(&ev0_));
 	HIPCHK(hipEventCreate(&ev1_));
 
+	h_target_.assign(target, target + 3 * M);
 	sse_thresh_ = p_.mse_threshold * (float)N_;      // jly_goicp.cpp:208 (inlierNum = Nd)
 	icp_err_diff_ = p_.mse_threshold / 10000;        // jly_goicp.cpp:186
 

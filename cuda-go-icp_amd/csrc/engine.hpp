@@ -98,6 +98,7 @@ public:
 	void dt_download(float* grid_linear);        // V^3, [z][y][x]
 	size_t n_source() const { return N_; }
 	size_t n_target() const { return M_; }
+	const float* target_xyz() const { return h_target_.data(); }
 	float sse_threshold() const { return sse_thresh_; }
 	float rot_coeff(int level) const;
 	hipStream_t stream() const { return stream_; }
@@ -125,6 +126,7 @@ private:
 	float4* d_src_ = nullptr;         // N  (x,y,z,|p|), Morton order
 	std::vector<int32_t> src_perm_;   // sorted position -> original index
 	std::vector<float> h_src_sorted_; // N*4
+	std::vector<float> h_target_;     // M*3 (kept for viz.ply)
 	float src_centroid_[3] = {0, 0, 0}, model_centroid_[3] = {0, 0, 0};
 	DtDesc dt_{};
 	float* d_dt_ = nullptr;

@@ -242,6 +242,17 @@ int goicp_result_write_toml(goicp_handle h, const char* path)
 	return guarded([&] { goicp::write_result_toml(path, h->e->poll(), h->e->n_source(), h->e->n_target(), h->e->sse_threshold()); });
 }
 
+int goicp_result_write_ply(goicp_handle h, const char* path)
+{
+	REQUIRE(h && path);
+	return guarded([&] {
+		goicp::Result r = h->e->poll();
+		std::vector<float> moved(3 * h->e->n_source());
+		h->e->source_transformed(r.optR, r.optT, moved.data());
+		goicp::write_viz_ply(path, h->e->target_xyz(), h->e->n_target(), moved.data(), h->e->n_source());
+	});
+}
+
 int goicp_transform_source(goicp_handle h, const float R[9], const float t[3], float* out_xyz)
 {
 	REQUIRE(h && R && t && out_xyz);

@@ -263,6 +263,9 @@ class FastGoICP:
     def write_output(self, path):
         B.check(self.registration._lib.goicp_result_write_toml(self.registration.handle, str(path).encode()))
 
+    def write_visualization(self, path):
+        B.check(self.registration._lib.goicp_result_write_ply(self.registration.handle, str(path).encode()))
+
     # stepped API used by the sharded driver
     def set_shard(self, rank, world):
         B.check(self.registration._lib.goicp_set_shard(self.registration.handle, rank, world))

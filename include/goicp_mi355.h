@@ -189,6 +189,9 @@ typedef struct goicp_result {
 int goicp_poll(goicp_handle h, goicp_result* out);
 /* the output.toml the reference's configs promise (test/bunny_goicp.toml:12) but never write */
 int goicp_result_write_toml(goicp_handle h, const char* path);
+/* the viz.ply the reference's configs promise (test/bunny_goicp.toml:13) but never write: binary
+ * little-endian PLY, target points (grey) followed by the source under optR|optT (red) */
+int goicp_result_write_ply(goicp_handle h, const char* path);
 /* source cloud under (R,t), original point order (what src/goicp_kernel.cu:181-193 draws) */
 int goicp_transform_source(goicp_handle h, const float R[9], const float t[3], float* out_xyz);
 

@@ -164,6 +164,7 @@ public:
 		finished = r.finished != 0;
 	}
 	void write_output(const std::string& path) { check(goicp_result_write_toml(registration.handle(), path.c_str())); }
+	void write_visualization(const std::string& path) { check(goicp_result_write_ply(registration.handle(), path.c_str())); }
 
 	Mat3 curR{}, optR{};
 	Vec3 curT{}, optT{};

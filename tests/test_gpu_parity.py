@@ -211,6 +211,24 @@ def test_nn_vs_bruteforce(reg10, oracle_mod, bunny_model):
     assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
 
 
+def test_nn_three_level_hierarchy(pkg, oracle_mod):
+    """M = 120 000 > 64*64*16 exercises the K = 3 box hierarchy (BASELINE configs[2]/[4] sizes): exact vs
+    brute force, including queries far outside the cloud and outside the DT grid."""
+    from cuda_go_icp_amd import synth
+    target, source, _, _ = synth.make_pair(seed=77, M=120000, N=2000)
+    reg = pkg.Registration(target, source, 1e-3, dt_size=128)
+    rng = np.random.default_rng(5)
+    q = np.concatenate([source, rng.uniform(-3, 3, (1000, 3)).astype(np.float32), target[:500]])
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    err, R, t = pkg.IterativeClosestPoint3D(reg, 5, 1e-9).run()            # and the fused pass agrees with the oracle ICP
+    kd = oracle_mod.KdTree(target)
+    oerr, oR, ot, _ = kd.icp_run(source, np.eye(3), np.zeros(3), 5, 1e-9)
+    assert abs(err - oerr) <= 1e-3 * oerr and np.abs(R - oR).max() <= 1e-4 and np.abs(t - ot).max() <= 1e-4
+    reg.close()
+
+
 def test_icp_run_golden(pkg, reg10):
     """IterativeClosestPoint3D::run / ICP3D::Run with forced iteration counts: 1e-4 abs on R,t for
     <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3."""
@@ -289,6 +307,13 @@ def test_e2e_bunny_full_wide(pkg, bunny_model, bunny_data, tmp_path):
     eng.write_output(out)
     txt = out.read_text()
     assert "rotation" in txt and "translation" in txt and "sse" in txt
+    viz = tmp_path / "viz.ply"
+    eng.write_visualization(viz)
+    back = pkg.load_cloud(viz)                        # our own loader reads it back: target + moved source
+    assert back.shape == (len(bunny_model) + len(bunny_data), 3)
+    assert np.array_equal(back[:len(bunny_model)], bunny_model)
+    moved = eng.registration.transform_source(eng.optR, eng.optT)
+    assert np.array_equal(back[len(bunny_model):], moved)
 
 
 def test_e2e_bunny_full_reference_order(pkg, bunny_model, bunny_data):

@@ -48,6 +48,7 @@ def main():
         print(name, n, "points")
     procs = [
         subprocess.Popen([h, "units", OUT, mb, db, "10"], stdout=subprocess.DEVNULL),
+        subprocess.Popen([h, "trim", OUT, mb, db, "10", "0.1"], stdout=subprocess.DEVNULL),
         subprocess.Popen([h, "e2e", OUT, "rand100", mr, dr, "1e-3", "1"], stdout=subprocess.DEVNULL),
         subprocess.Popen([h, "e2e", OUT, "bunny10", mb, db, "1e-3", "10"], stdout=subprocess.DEVNULL),
     ]

@@ -303,6 +303,37 @@ void orc_rotate(const float R[9], const float* d, int N, float* o)
 /* ------------------------------------------------------------------------------------------
  * Cube bounds and inner (translation) BnB
  * ------------------------------------------------------------------------------------------ */
+static int cmp_float_asc(const void* a, const void* b)
+{
+	float fa = *(const float*)a, fb = *(const float*)b;
+	return (fa > fb) - (fa < fb);
+}
+
+void orc_cube_bound_trim(const orc_dt* dt, const float* p, int N, const float* rho,
+                         float tx, float ty, float tz, float w_child, int inliers, float* ub_out, float* lb_out)
+{
+	/* jly_goicp.cpp:276-315 with trimming: the inlierNum smallest residuals (intro_select, :298) enter the sums.
+	 * Any exact selection gives the same multiset; sorted order is used for the sums. */
+	float maxTransDis = (float)(ORC_SQRT3 / 2.0 * (double)w_child);
+	float* m = (float*)malloc(sizeof(float) * N);
+	for (int i = 0; i < N; i++) {
+		float v = orc_dt_distance(dt, (double)(p[3 * i] + tx), (double)(p[3 * i + 1] + ty), (double)(p[3 * i + 2] + tz));
+		if (rho) v -= rho[i];
+		if (v < 0) v = 0;
+		m[i] = v;
+	}
+	if (inliers < N) qsort(m, N, sizeof(float), cmp_float_asc);
+	float ub = 0, lb = 0;
+	for (int i = 0; i < inliers; i++) {
+		ub += m[i] * m[i];
+		float dis = m[i] - maxTransDis;
+		if (dis > 0) lb += dis * dis;
+	}
+	free(m);
+	*ub_out = ub;
+	*lb_out = lb;
+}
+
 void orc_cube_bound(const orc_dt* dt, const float* p, int N, const float* rho,
                     float tx, float ty, float tz, float w_child, float* ub_out, float* lb_out)
 {
@@ -364,9 +395,17 @@ float orc_dt_sse(const orc_dt* dt, const float* d, int N, const float R[9], cons
 	return error;
 }
 
+float orc_inner_bnb_trim(const orc_dt* dt, const float* p, int N, const float* rho, int inliers, float incumbent, float sse_thresh, const float root[4], float best_node[4], long long* pops, long long* cubes);
 float orc_inner_bnb(const orc_dt* dt, const float* p, int N, const float* rho,
                     float incumbent, float sse_thresh, const float root[4],
                     float best_node[4], long long* pops, long long* cubes)
+{
+	return orc_inner_bnb_trim(dt, p, N, rho, N, incumbent, sse_thresh, root, best_node, pops, cubes);
+}
+
+float orc_inner_bnb_trim(const orc_dt* dt, const float* p, int N, const float* rho, int inliers,
+                         float incumbent, float sse_thresh, const float root[4],
+                         float best_node[4], long long* pops, long long* cubes)
 {
 	/* jly_goicp.cpp:227-340 */
 	heap_t q;
@@ -388,7 +427,8 @@ float orc_inner_bnb(const orc_dt* dt, const float* p, int N, const float* rho,
 			c.z = parent.z + (j >> 2 & 1) * c.w;
 			float tx = c.x + c.w / 2, ty = c.y + c.w / 2, tz = c.z + c.w / 2;
 			float ub, lb;
-			orc_cube_bound(dt, p, N, rho, tx, ty, tz, c.w, &ub, &lb);
+			if (inliers < N) orc_cube_bound_trim(dt, p, N, rho, tx, ty, tz, c.w, inliers, &ub, &lb);
+			else orc_cube_bound(dt, p, N, rho, tx, ty, tz, c.w, &ub, &lb);
 			ncube++;
 			if (ub < optErrorT) {
 				optErrorT = ub;

@@ -56,6 +56,12 @@ void  orc_rotate(const float R[9], const float* data_xyz, int N, float* out_xyz)
 /* jly_goicp.cpp:262-315 for one child cube with centre (tx,ty,tz) and width w_child */
 void  orc_cube_bound(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null,
                      float tx, float ty, float tz, float w_child, float* ub, float* lb);
+/* trimmed form (trimFraction > 0, jly_goicp.cpp:293-315): only the `inliers` smallest residuals are summed */
+void  orc_cube_bound_trim(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null,
+                          float tx, float ty, float tz, float w_child, int inliers, float* ub, float* lb);
+float orc_inner_bnb_trim(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null, int inliers,
+                         float incumbent, float sse_thresh, const float root[4],
+                         float best_node[4], long long* pops, long long* cubes);
 /* same arithmetic per point, OpenMP over points (sum order differs); for the all-core CPU baseline */
 void  orc_cube_bound_omp(const orc_dt* dt, const float* prot_xyz, int N, const float* rho_or_null,
                          float tx, float ty, float tz, float w_child, float* ub, float* lb);

@@ -53,6 +53,10 @@ def lib():
         L.orc_rotate.argtypes = [fp, fp, C.c_int, fp]
         L.orc_cube_bound.argtypes = [dp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp]
         L.orc_cube_bound_omp.argtypes = L.orc_cube_bound.argtypes
+        L.orc_cube_bound_trim.argtypes = [dp, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp, fp]
+        L.orc_inner_bnb_trim.argtypes = [dp, fp, C.c_int, fp, C.c_int, C.c_float, C.c_float, fp, fp,
+                                         C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.orc_inner_bnb_trim.restype = C.c_float
         L.orc_cube_bounds_batch.argtypes = [dp, fp, C.c_int, fp, fp, C.c_int, fp, fp, C.c_int]
         L.orc_dt_sse.argtypes = [dp, fp, C.c_int, fp, fp]
         L.orc_dt_sse.restype = C.c_float
@@ -174,6 +178,31 @@ def cube_bound(dt, prot, rho, t, w_child, omp=False):
     fn(C.byref(dt.dt), pp, len(p), rp, np.float32(t[0]), np.float32(t[1]), np.float32(t[2]), np.float32(w_child),
        C.byref(ub), C.byref(lb))
     return np.float32(ub.value), np.float32(lb.value)
+
+
+def cube_bound_trim(dt, prot, rho, t, w_child, inliers):
+    p, pp = _f(prot)
+    rp = None
+    if rho is not None:
+        rho, rp = _f(rho)
+    ub, lb = C.c_float(), C.c_float()
+    lib().orc_cube_bound_trim(C.byref(dt.dt), pp, len(p), rp, float(np.float32(t[0])), float(np.float32(t[1])),
+                              float(np.float32(t[2])), float(np.float32(w_child)), int(inliers), C.byref(ub), C.byref(lb))
+    return np.float32(ub.value), np.float32(lb.value)
+
+
+def inner_bnb_trim(dt, prot, rho, inliers, incumbent, sse_thresh, root=(-0.5, -0.5, -0.5, 1.0)):
+    p, pp = _f(prot)
+    rp = None
+    if rho is not None:
+        rho, rp = _f(rho)
+    root_, rootp = _f(np.asarray(root))
+    best = np.zeros(4, np.float32)
+    pops, cubes = C.c_longlong(0), C.c_longlong(0)
+    v = lib().orc_inner_bnb_trim(C.byref(dt.dt), pp, len(p), rp, int(inliers), float(np.float32(incumbent)),
+                                 float(np.float32(sse_thresh)), rootp, best.ctypes.data_as(C.POINTER(C.c_float)),
+                                 C.byref(pops), C.byref(cubes))
+    return np.float32(v), best, pops.value, cubes.value
 
 
 def cube_bounds_batch(dt, prot, rho, cubes4, parallel=False):

@@ -15,6 +15,7 @@
 //   e2e    <outdir> <tag> <model.txt> <data.txt> <mse> <stride>
 //   units  <outdir> <model.txt> <data.txt> <stride>
 //   cloud  <out.f32> <cloud.txt>
+//   trim   <outdir> <model.txt> <data.txt> <stride> <trim_fraction>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -374,6 +375,88 @@ static int cmd_units(int argc, char** argv)
 	return 0;
 }
 
+// ---------------------------------------------------------------- trimmed bounds (trimFraction > 0)
+// GoICP::trimFraction is a public field (jly_goicp.h:116) the reference hard-wires to 0 (jly_goicp.cpp:55);
+// setting it before Initialize() drives the reference's own trimmed InnerBnB (jly_goicp.cpp:293-315).
+static int cmd_trim(int argc, char** argv)
+{
+	if (argc < 7) return 1;
+	std::string outdir = argv[2];
+	auto model = load_txt(argv[3], 1);
+	int stride = atoi(argv[5]);
+	float frac = (float)atof(argv[6]);
+	auto data = load_txt(argv[4], stride);
+	mse_threshold = 1e-3f;
+	GoICP g(1e-3f);
+	g.pModel = model.data(); g.Nm = (int)model.size();
+	g.pData = data.data();   g.Nd = (int)data.size();
+	g.trimFraction = frac;
+	g.BuildDT();
+	g.Initialize();
+	const int N = g.Nd;
+	std::mt19937 rng(424242u);
+	const float rotv[2][3] = { { 0.3f, -0.2f, 0.9f }, { -2.1f, 0.4f, 1.1f } };
+	FILE* f = fopen((outdir + "/inner_bnb_trim.json").c_str(), "w");
+	fprintf(f, "{\n\"Nd\": %d, \"stride\": %d, \"inlierNum\": %d,\n", N, stride, g.inlierNum);
+	jf(f, "trim_fraction", frac);
+	jf(f, "sse_threshold", g.SSEThresh);
+	fprintf(f, "\"cases\": [\n");
+	TRANSNODE rootT = g.initNodeTrans;
+	float sseT = g.SSEThresh;
+	std::uniform_real_distribution<float> uc(-0.5f, 0.5f);
+	for (int r = 0; r < 2; r++) {
+		float R[9];
+		rodrigues(rotv[r], R);
+		for (int i = 0; i < N; i++) {
+			POINT3D& p = g.pData[i];
+			g.pDataTemp[i].x = R[0] * p.x + R[1] * p.y + R[2] * p.z;
+			g.pDataTemp[i].y = R[3] * p.x + R[4] * p.y + R[5] * p.z;
+			g.pDataTemp[i].z = R[6] * p.x + R[7] * p.y + R[8] * p.z;
+		}
+		fprintf(f, "{");
+		jarrf(f, "R", R, 9);
+		fprintf(f, "\"single\": [\n");
+		for (int c = 0; c < 32; c++) {
+			int lev = c % 7;
+			TRANSNODE parent;
+			parent.w = 1.0f / (float)(1 << lev);
+			parent.x = uc(rng) * (1 - parent.w) - parent.w / 2;
+			parent.y = uc(rng) * (1 - parent.w) - parent.w / 2;
+			parent.z = uc(rng) * (1 - parent.w) - parent.w / 2;
+			parent.lb = 0; parent.ub = 0;
+			for (int pass = 0; pass < 2; pass++) {
+				int level = 3 + (c % 5);
+				g.initNodeTrans = parent;
+				g.optError = 1e10f;
+				g.SSEThresh = 1e9f;
+				TRANSNODE best; best.x = best.y = best.z = best.w = 0;
+				float v = g.InnerBnB(pass ? g.maxRotDis[level] : NULL, &best);
+				fprintf(f, "{\"parent\": [%.9g, %.9g, %.9g, %.9g], \"level\": %d, \"min_ub\": %.9g, "
+				           "\"best\": [%.9g, %.9g, %.9g, %.9g]}%s\n",
+				        parent.x, parent.y, parent.z, parent.w, pass ? level : -1, v,
+				        best.x, best.y, best.z, best.w, (c == 31 && pass == 1) ? "" : ",");
+			}
+		}
+		fprintf(f, "],\n");
+		g.initNodeTrans = rootT;
+		g.SSEThresh = sseT;
+		fprintf(f, "\"full\": [\n");
+		for (int pass = 0; pass < 2; pass++) {
+			int level = 6 + r;
+			g.optError = 1e10f;
+			TRANSNODE best; best.x = best.y = best.z = best.w = 0;
+			long long c0 = tNodeCount;
+			float v = g.InnerBnB(pass ? g.maxRotDis[level] : NULL, &best);
+			fprintf(f, "{\"incumbent\": 1e10, \"level\": %d, \"value\": %.9g, \"best\": [%.9g, %.9g, %.9g, %.9g], \"pops\": %lld}%s\n",
+			        pass ? level : -1, v, best.x, best.y, best.z, best.w, tNodeCount - c0, pass == 1 ? "" : ",");
+		}
+		fprintf(f, "]}%s\n", r == 1 ? "" : ",");
+	}
+	fprintf(f, "]\n}\n");
+	fclose(f);
+	return 0;
+}
+
 // ---------------------------------------------------------------- cloud -> float32 blob
 static int cmd_cloud(int argc, char** argv)
 {
@@ -392,5 +475,6 @@ int main(int argc, char** argv)
 	if (!strcmp(argv[1], "e2e")) return cmd_e2e(argc, argv);
 	if (!strcmp(argv[1], "units")) return cmd_units(argc, argv);
 	if (!strcmp(argv[1], "cloud")) return cmd_cloud(argc, argv);
+	if (!strcmp(argv[1], "trim")) return cmd_trim(argc, argv);
 	return 1;
 }

@@ -158,3 +158,25 @@ def test_e2e_bunny10(oracle_mod, bunny_model, bunny_data10):
     r, g = _check_e2e(oracle_mod, "bunny10", bunny_model, bunny_data10)
     assert r["rot_pops"] == g["rNodeCount"]
     assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]
+
+
+def test_inner_bnb_trimmed(oracle_mod, oracle_dt_bunny, bunny_data10):
+    """trimFraction = 0.1 (GoICP::trimFraction set in the harness): the reference's own trimmed InnerBnB
+    (jly_goicp.cpp:293-315).  Single expansions rel 1e-4 + same arg-min child; full searches: value rel
+    1e-3, node pops within 1 %."""
+    g = golden("inner_bnb_trim")
+    k = g["inlierNum"]
+    assert k == int(len(bunny_data10) * (1 - np.float32(g["trim_fraction"])))
+    _, rho = oracle_mod.rot_radii(bunny_data10)
+    for case in g["cases"]:
+        prot = oracle_mod.rotate(np.array(case["R"], dtype=np.float32).reshape(3, 3), bunny_data10)
+        for s in case["single"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, cubes = oracle_mod.inner_bnb_trim(oracle_dt_bunny, prot, r, k, 1e10, 1e9, root=s["parent"])
+            assert cubes == 8 and abs(v - s["min_ub"]) <= 1e-4 * max(s["min_ub"], 1e-3)
+            assert np.array_equal(best, np.array(s["best"], dtype=np.float32))
+        for s in case["full"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, _ = oracle_mod.inner_bnb_trim(oracle_dt_bunny, prot, r, k, s["incumbent"], g["sse_threshold"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(pops - s["pops"]) <= max(2, 0.01 * s["pops"])

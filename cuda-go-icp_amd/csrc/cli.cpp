@@ -1,5 +1,5 @@
 // goicp_cli: headless replacement for the reference's viewer main (src/main.cpp:14-187).  Takes the
-// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--verbose] [--seed S]
+// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S]
 //   modes 0/1/2 (plain ICP, src/main.cpp:99-110): N ICP iterations (the reference iterates forever; default 50)
 //   modes 3/4   (Go-ICP,   src/main.cpp:111-141): full registration
 // Prints the result the way the reference logs it and writes io.output (output.toml) when set.
@@ -26,12 +26,14 @@ static std::string resolve(const std::string& p, const std::string& toml)
 
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--verbose] [--seed S]\n"); return 2; }
+	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S]\n"); return 2; }
 	int iters = 50, verbose = 0;
+	float trim_fraction = 0.f;   // the TOML's `trim = true` carries no fraction (the reference ignores it): given here
 	unsigned long long seed = 0;
 	for (int i = 2; i < argc; i++) {
 		if (!std::strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
+		else if (!std::strcmp(argv[i], "--trim-fraction") && i + 1 < argc) trim_fraction = (float)std::atof(argv[++i]);
 		else if (!std::strcmp(argv[i], "--verbose")) verbose = 1;
 	}
 	try {
@@ -44,6 +46,7 @@ int main(int argc, char** argv)
 		goicp_params p;
 		goicp_params_default(&p);
 		p.verbose = verbose;
+		p.trim_fraction = trim_fraction;
 		std::mutex mtx;
 		icp::FastGoICP engine(target, source, config.mse_threshold, mtx, &p);
 		goicp_handle h = engine.registration.handle();

@@ -265,6 +265,127 @@ __global__ void bounds_finalize(const float* __restrict__ scratch, int B, int gr
 	(k < kGroup ? ub_out : lb_out)[c] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Trimmed cube bounds (trimFraction > 0; jly_goicp.cpp:293-315): only the `inliers` smallest clamped
+// residuals of a cube enter the two sums.  One workgroup owns 8 cubes and ALL points; the k-th
+// smallest residual of each cube is found exactly by a 3-digit radix select on the float bit
+// pattern (11+11+9 bits, integer LDS histograms -> deterministic), recomputing the residuals in
+// every pass instead of storing B x N floats; a fourth pass sums the residuals below the threshold
+// T, and the `rem` copies of T itself are added once.
+// ------------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
+    const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
+    const CubeRec* __restrict__ cubes, int B, int inliers, float* __restrict__ ub_out, float* __restrict__ lb_out)
+{
+	__shared__ unsigned hist[kGroup][2048];
+	__shared__ unsigned sel_prefix[kGroup], sel_rem[kGroup];
+	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
+	const int c0 = blockIdx.x * kGroup;
+	CubeRec cr[kGroup];
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) cr[c] = cubes[c0 + c < B ? c0 + c : B - 1];
+	if (threadIdx.x < kGroup) { sel_prefix[threadIdx.x] = 0u; sel_rem[threadIdx.x] = (unsigned)inliers; }
+
+	auto residual = [&](const float4& p, int c) -> float {
+		const Rot9 R = rots[cr[c].rot];
+		const float rx = R.r[0] * p.x + R.r[1] * p.y + R.r[2] * p.z;
+		const float ry = R.r[3] * p.x + R.r[4] * p.y + R.r[5] * p.z;
+		const float rz = R.r[6] * p.x + R.r[7] * p.y + R.r[8] * p.z;
+		float m = dt_distance<LAYOUT>(dt, rx + cr[c].tx, ry + cr[c].ty, rz + cr[c].tz);
+		m = m - cr[c].coeff * p.w;
+		return m < 0.f ? 0.f : m;
+	};
+
+#pragma unroll 1
+	for (int pass = 0; pass < 3; pass++) {
+		const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), width = pass == 2 ? 9 : 11, bins = 1 << width;
+		for (int i = threadIdx.x; i < kGroup * 2048; i += kBoundsThreads) (&hist[0][0])[i] = 0u;
+		__syncthreads();
+		for (int i = threadIdx.x; i < N; i += kBoundsThreads) {
+			const float4 p = src[i];
+#pragma unroll
+			for (int c = 0; c < kGroup; c++) {
+				const unsigned key = __float_as_uint(residual(p, c));
+				if (pass == 0 || (key >> (shift + width)) == sel_prefix[c])
+					atomicAdd(&hist[c][(key >> shift) & (unsigned)(bins - 1)], 1u);
+			}
+		}
+		__syncthreads();
+		// 32 threads per cube: locate the bin holding the rem-th smallest of the surviving candidates
+		{
+			const int c = threadIdx.x >> 5, j = threadIdx.x & 31, per = bins >> 5;
+			unsigned local = 0;
+			for (int b = j * per; b < (j + 1) * per; b++) local += hist[c][b];
+			unsigned incl = local;
+#pragma unroll
+			for (int off = 1; off < 32; off <<= 1) {
+				const unsigned o = __shfl_up(incl, off, 32);
+				if (j >= off) incl += o;
+			}
+			const unsigned excl = incl - local, rem = sel_rem[c];
+			if (excl < rem && rem <= incl) {
+				unsigned cum = excl;
+				for (int b = j * per; b < (j + 1) * per; b++) {
+					const unsigned h = hist[c][b];
+					if (cum < rem && rem <= cum + h) {
+						sel_prefix[c] = (sel_prefix[c] << width) | (unsigned)b;
+						sel_rem[c] = rem - cum;
+						break;
+					}
+					cum += h;
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	float ub[kGroup], lb[kGroup];
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) { ub[c] = 0.f; lb[c] = 0.f; }
+	for (int i = threadIdx.x; i < N; i += kBoundsThreads) {
+		const float4 p = src[i];
+#pragma unroll
+		for (int c = 0; c < kGroup; c++) {
+			const float m = residual(p, c);
+			if (__float_as_uint(m) < sel_prefix[c]) {        // strictly below the k-th smallest
+				ub[c] += m * m;
+				const float dis = fmaxf(m - cr[c].delta, 0.f);
+				lb[c] += dis * dis;
+			}
+		}
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) {
+		const float u = wave_sum(ub[c]), l = wave_sum(lb[c]);
+		if (lane == 0) { red[wave][c] = u; red[wave][kGroup + c] = l; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 2 * kGroup) {
+		float s = red[0][threadIdx.x];
+#pragma unroll
+		for (int w = 1; w < kBoundsThreads / 64; w++) s += red[w][threadIdx.x];
+		const int c = threadIdx.x & (kGroup - 1);
+		// the residuals equal to the threshold: sel_rem copies of T
+		const float T = __uint_as_float(sel_prefix[c]);
+		const float n_eq = (float)sel_rem[c];
+		if (threadIdx.x < kGroup) s += n_eq * (T * T);
+		else { const float dis = fmaxf(T - cubes[c0 + c < B ? c0 + c : B - 1].delta, 0.f); s += n_eq * (dis * dis); }
+		if (c0 + c < B) (threadIdx.x < kGroup ? ub_out : lb_out)[c0 + c] = s;
+	}
+}
+
+hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, int B,
+                              int inliers, float* ub, float* lb, hipStream_t stream)
+{
+	if (B <= 0 || N <= 0) return hipSuccess;
+	const dim3 grid((B + kGroup - 1) / kGroup), block(kBoundsThreads);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, B, inliers, ub, lb);
+	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, B, inliers, ub, lb);
+	return hipGetLastError();
+}
+
 static void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts)
 {
 	int g = (B + kGroup - 1) / kGroup;
@@ -467,6 +588,117 @@ __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __r
 	}
 }
 
+// ---- trimmed ICP (trim_fraction > 0; jly_icp3d.hpp:236-252): NN for every point, exact selection of
+// the `num` smallest squared distances (radix select, ties in point order), sums over the selected ----
+template <int K, int LAYOUT>
+__global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const float4* __restrict__ src, int N,
+                                                             const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
+                                                             float* __restrict__ nn_d2, int* __restrict__ nn_slot)
+{
+	if (st->converged) return;
+	const int lane = threadIdx.x & 63;
+	const int w = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);
+	for (int j = 0; j < kIcpQueriesPerWave; j++) {
+		const int i = w * kIcpQueriesPerWave + j;
+		if (i >= N) break;
+		const float4 p = src[i];
+		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+		const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
+		if (lane == 0) { nn_d2[i] = r.best; nn_slot[i] = r.slot; }
+	}
+}
+
+// one workgroup: key of the num-th smallest d2 (3-digit radix select), then inclusion flags with the
+// ties taken in point order (deterministic)
+__global__ __launch_bounds__(1024) void icp_select_kernel(const float* __restrict__ nn_d2, int N, int num,
+                                                          const IcpState* __restrict__ st, unsigned char* __restrict__ include)
+{
+	if (st->converged) return;
+	__shared__ unsigned hist[2048];
+	__shared__ unsigned sel_prefix, sel_rem, wave_cnt[16], tie_base;
+	if (threadIdx.x == 0) { sel_prefix = 0u; sel_rem = (unsigned)num; tie_base = 0u; }
+#pragma unroll 1
+	for (int pass = 0; pass < 3; pass++) {
+		const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), width = pass == 2 ? 9 : 11, bins = 1 << width;
+		for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0u;
+		__syncthreads();
+		for (int i = threadIdx.x; i < N; i += 1024) {
+			const unsigned key = __float_as_uint(nn_d2[i]);
+			if (pass == 0 || (key >> (shift + width)) == sel_prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(bins - 1)], 1u);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {     // 2048 bins, once per pass: a serial scan is negligible next to the N-element passes
+			unsigned cum = 0, rem = sel_rem;
+			for (int b = 0; b < bins; b++) {
+				const unsigned h = hist[b];
+				if (cum < rem && rem <= cum + h) { sel_prefix = (sel_prefix << width) | (unsigned)b; sel_rem = rem - cum; break; }
+				cum += h;
+			}
+		}
+		__syncthreads();
+	}
+	const unsigned T = sel_prefix, rem = sel_rem;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int base = 0; base < N; base += 1024) {
+		const int i = base + threadIdx.x;
+		const unsigned key = i < N ? __float_as_uint(nn_d2[i]) : 0xffffffffu;
+		const bool tie = key == T;
+		const unsigned long long tb = __ballot(tie);
+		if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(tb);
+		__syncthreads();
+		unsigned before = tie_base;
+		for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2];
+		before += (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
+		if (i < N) include[i] = (key < T || (tie && before < rem)) ? 1 : 0;
+		__syncthreads();
+		if (threadIdx.x == 0) { unsigned t = 0; for (int w2 = 0; w2 < 16; w2++) t += wave_cnt[w2]; tie_base += t; }
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(kIcpThreads) void icp_accum_kernel(const float4* __restrict__ src, int N,
+                                                                const IcpState* __restrict__ st, KdDesc kd,
+                                                                const float* __restrict__ nn_d2, const int* __restrict__ nn_slot,
+                                                                const unsigned char* __restrict__ include, float* __restrict__ partials)
+{
+	__shared__ float red[kIcpThreads / 64][kIcpAcc];
+	if (st->converged) return;
+	const int i = blockIdx.x * kIcpThreads + threadIdx.x;
+	float acc[kIcpAcc];
+#pragma unroll
+	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
+	if (i < N && include[i]) {
+		const float4 p = src[i];
+		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+		const float4 m = kd.pts[nn_slot[i]];
+		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];
+		const float bx = m.x - st->cm[0], by = m.y - st->cm[1], bz = m.z - st->cm[2];
+		acc[0] = ax; acc[1] = ay; acc[2] = az;
+		acc[3] = bx; acc[4] = by; acc[5] = bz;
+		acc[6] = ax * bx; acc[7] = ax * by; acc[8] = ax * bz;
+		acc[9] = ay * bx; acc[10] = ay * by; acc[11] = ay * bz;
+		acc[12] = az * bx; acc[13] = az * by; acc[14] = az * bz;
+		acc[15] = nn_d2[i];
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < kIcpAcc; k++) {
+		const float s = wave_sum(acc[k]);
+		if (lane == 0) red[wave][k] = s;
+	}
+	__syncthreads();
+	if (threadIdx.x < kIcpAcc) {
+		float s = red[0][threadIdx.x];
+#pragma unroll
+		for (int x = 1; x < kIcpThreads / 64; x++) s += red[x][threadIdx.x];
+		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = s;
+	}
+}
+
 // ---- 3x3 SVD (one-sided Jacobi, double) -> Kabsch rotation, on the device ---------------------------
 __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 {
@@ -630,6 +862,29 @@ static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& 
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
 	if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
 	else hipLaunchKernelGGL((icp_pass_kernel<K, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+}
+
+template <int K>
+static void launch_nn_store_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* d2, int* slot, hipStream_t stream)
+{
+	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
+	if (dt.layout) hipLaunchKernelGGL((icp_nn_kernel<K, 1>), grid, block, 0, stream, src, N, st, kd, dt, d2, slot);
+	else hipLaunchKernelGGL((icp_nn_kernel<K, 0>), grid, block, 0, stream, src, N, st, kd, dt, d2, slot);
+}
+
+int icp_trim_blocks(int N) { return (N + kIcpThreads - 1) / kIcpThreads; }
+
+hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* st, const KdDesc& kd, const DtDesc& dt,
+                                     float* nn_d2, int* nn_slot, unsigned char* include, float* partials, hipStream_t stream)
+{
+	if (kd.K == 1) launch_nn_store_k<1>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
+	else if (kd.K == 2) launch_nn_store_k<2>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
+	else launch_nn_store_k<3>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
+	hipLaunchKernelGGL(icp_select_kernel, dim3(1), dim3(1024), 0, stream, nn_d2, N, num, st, include);
+	const int nb = icp_trim_blocks(N);
+	hipLaunchKernelGGL(icp_accum_kernel, dim3(nb), dim3(kIcpThreads), 0, stream, src, N, st, kd, nn_d2, nn_slot, include, partials);
+	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, nb, st);
+	return hipGetLastError();
 }
 
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,

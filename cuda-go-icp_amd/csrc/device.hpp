@@ -62,6 +62,10 @@ size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out);
 hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes,
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream);
 
+// trimmed form: only the `inliers` smallest residuals of each cube are summed (jly_goicp.cpp:293-315)
+hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, int B,
+                              int inliers, float* ub, float* lb, hipStream_t stream);
+
 // ---- ICP ------------------------------------------------------------------------------------
 // Device-resident state of the ICP loop (ICP3D<float>::Run, jly_icp3d.hpp:181-295).  One
 // iteration = icp_pass_kernel (transform, exact 1-NN, pivoted sums) + icp_finalize_update
@@ -82,6 +86,10 @@ struct IcpState {
 int icp_blocks(int N);           // workgroups per pass; partials must hold icp_blocks(N)*kIcpAcc floats
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
                                 float* partials, hipStream_t stream);
+// trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
+int icp_trim_blocks(int N);
+hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
+                                     float* nn_d2, int* nn_slot, unsigned char* include, float* partials, hipStream_t stream);
 // In-place p <- R p + t, norm recomputed (ICP::kdTreeGPUStep's kernTransform, icp_kernel.cu:138-144)
 hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t stream);
 // NN operator on arbitrary queries (kernKDSearchNearest, icp_kernel.cu:146-157)

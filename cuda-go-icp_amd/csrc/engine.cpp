@@ -85,7 +85,10 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	HIPCHK(hipEventCreate(&ev1_));
 
 	h_target_.assign(target, target + 3 * M);
-	sse_thresh_ = p_.mse_threshold * (float)N_;      // jly_goicp.cpp:208 (inlierNum = Nd)
+	if (!(p_.trim_fraction >= 0.f) || p_.trim_fraction >= 1.f) throw std::invalid_argument("goicp: trim_fraction must be in [0,1)");
+	inliers_ = (int)((float)N_ * (1 - p_.trim_fraction));    // jly_goicp.cpp:201
+	if (inliers_ < 1) inliers_ = 1;
+	sse_thresh_ = p_.mse_threshold * (float)inliers_;         // jly_goicp.cpp:208
 	icp_err_diff_ = p_.mse_threshold / 10000;        // jly_goicp.cpp:186
 
 	// rotation uncertainty coefficients per level (jly_goicp.cpp:153-159)
@@ -208,7 +211,12 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 		HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
 		kd_.pts = d_kd_pts_; kd_.K = kh.K; kd_.M = (int)M_;
 	}
-	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)icp_blocks((int)N_) * kIcpAcc));
+	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)std::max(icp_blocks((int)N_), icp_trim_blocks((int)N_)) * kIcpAcc));
+	if (inliers_ < (int)N_) {
+		HIPCHK(hipMalloc(&d_nn_d2_, sizeof(float) * N_));
+		HIPCHK(hipMalloc(&d_nn_slot_, sizeof(int) * N_));
+		HIPCHK(hipMalloc(&d_include_, N_));
+	}
 	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
 	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState)));
 	ensure_batch(4096, 64);
@@ -228,6 +236,7 @@ Engine::~Engine()
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
 	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_);
+	hipFree(d_nn_d2_); hipFree(d_nn_slot_); hipFree(d_include_);
 	hipEventDestroy(ev0_); hipEventDestroy(ev1_);
 	hipStreamDestroy(stream_);
 }
@@ -279,7 +288,10 @@ void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, 
 		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
 		cap_scratch_ = need;
 	}
-	HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
+	if (inliers_ < (int)N_)
+		HIPCHK(launch_bounds_trim(d_src_, (int)N_, dt_, d_rots, d_cubes, B, inliers_, d_ub, d_lb, s ? s : stream_));
+	else
+		HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
 	cnt_.bounds_launches++;
 }
 
@@ -401,11 +413,19 @@ void Engine::icp_state_init(const float R[9], const float t[3], float err_diff, 
 		st.cq[i] = R[3 * i] * src_centroid_[0] + R[3 * i + 1] * src_centroid_[1] + R[3 * i + 2] * src_centroid_[2] + t[i];
 	}
 	st.err = -1.f;
-	st.err_diff_n = err_diff * (float)N_;          // jly_icp3d.hpp:255: err_diff * num
-	st.n = (float)N_;
+	st.err_diff_n = err_diff * (float)inliers_;    // jly_icp3d.hpp:255: err_diff * num
+	st.n = (float)inliers_;                        // means over the num correspondences used (the reference divides by n, App. B-12)
 	st.carry_means = carry_means;
 	st.frozen = frozen;
 	HIPCHK(hipMemcpyAsync(d_icp_state_, h_icp_state_, sizeof(IcpState), hipMemcpyHostToDevice, stream_));
+}
+
+void Engine::icp_launch_one()
+{
+	if (inliers_ < (int)N_)
+		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
+	else
+		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
 }
 
 void Engine::icp_state_fetch()
@@ -421,7 +441,7 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 	int queued = 0;
 	while (queued < max_iter) {
 		const int k = std::min(chunk, max_iter - queued);
-		for (int i = 0; i < k; i++) HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+		for (int i = 0; i < k; i++) icp_launch_one();
 		queued += k;
 		icp_state_fetch();
 		if (h_icp_state_->converged || cancel_.load()) break;
@@ -439,10 +459,10 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
 {
 	icp_state_init(R, t, 0.f, 0, 1);   // frozen: every pass does the same work
-	HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+	icp_launch_one();
 	HIPCHK(hipStreamSynchronize(stream_));
 	HIPCHK(hipEventRecord(ev0_, stream_));
-	for (int i = 0; i < iters; i++) HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+	for (int i = 0; i < iters; i++) icp_launch_one();
 	HIPCHK(hipEventRecord(ev1_, stream_));
 	HIPCHK(hipEventSynchronize(ev1_));
 	float ms = 0.f;
@@ -454,7 +474,7 @@ void Engine::icp_step()
 {
 	// one iteration from the current step pose, fresh means, standard Kabsch (icp_kernel.cu:219-279)
 	icp_state_init(stepR_, stepT_, 0.f, 0, 0);
-	HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+	icp_launch_one();
 	icp_state_fetch();
 	std::memcpy(stepR_, h_icp_state_->R, sizeof(stepR_));
 	std::memcpy(stepT_, h_icp_state_->t, sizeof(stepT_));

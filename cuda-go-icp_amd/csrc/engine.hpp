@@ -27,6 +27,7 @@ struct Params {
 	int verbose = 0;
 	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
+	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 };
 
 struct Counters {
@@ -100,6 +101,7 @@ public:
 	size_t n_target() const { return M_; }
 	const float* target_xyz() const { return h_target_.data(); }
 	float sse_threshold() const { return sse_thresh_; }
+	int inliers() const { return inliers_; }
 	float rot_coeff(int level) const;
 	hipStream_t stream() const { return stream_; }
 	const float4* d_source() const { return d_src_; }
@@ -119,6 +121,7 @@ private:
 	Params p_;
 	size_t M_ = 0, N_ = 0;
 	float sse_thresh_ = 0.f, icp_err_diff_ = 0.f;
+	int inliers_ = 0;             // inlierNum = (int)(Nd * (1 - trimFraction)), jly_goicp.cpp:201
 	int rank_ = 0, world_ = 1;
 
 	hipStream_t stream_ = nullptr;
@@ -141,6 +144,8 @@ private:
 	float* d_scratch_ = nullptr;
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
+	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only
+	void icp_launch_one();
 	// nn query staging grows on demand
 	float rot_coeff_[20];
 

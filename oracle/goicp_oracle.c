@@ -16,6 +16,8 @@
 #define ORC_SQRT3 1.732050808
 #define ORC_MAXROTLEVEL 20
 
+static int cmp_float_asc(const void* a, const void* b);
+
 /* ------------------------------------------------------------------------------------------
  * Priority queue with the tie behaviour of libstdc++'s std::priority_queue (push_heap /
  * pop_heap = bottom-up hole percolation + sift-up), so that node visit order -- and with it the
@@ -380,6 +382,24 @@ void orc_cube_bounds_batch(const orc_dt* dt, const float* p, int N, const float*
 		orc_cube_bound(dt, p, N, rho, cubes4[4 * b], cubes4[4 * b + 1], cubes4[4 * b + 2], cubes4[4 * b + 3], &ub[b], &lb[b]);
 }
 
+float orc_dt_sse_trim(const orc_dt* dt, const float* d, int N, const float R[9], const float t[3], int inliers)
+{
+	/* jly_goicp.cpp:100-129 with trimming: the inlierNum smallest distances */
+	float* m = (float*)malloc(sizeof(float) * N);
+	for (int i = 0; i < N; i++) {
+		float x = d[3 * i], y = d[3 * i + 1], z = d[3 * i + 2];
+		float qx = R[0] * x + R[1] * y + R[2] * z + t[0];
+		float qy = R[3] * x + R[4] * y + R[5] * z + t[1];
+		float qz = R[6] * x + R[7] * y + R[8] * z + t[2];
+		m[i] = orc_dt_distance(dt, qx, qy, qz);
+	}
+	if (inliers < N) qsort(m, N, sizeof(float), cmp_float_asc);
+	float error = 0;
+	for (int i = 0; i < inliers; i++) error += m[i] * m[i];
+	free(m);
+	return error;
+}
+
 float orc_dt_sse(const orc_dt* dt, const float* d, int N, const float R[9], const float t[3])
 {
 	/* jly_goicp.cpp:100-129 */
@@ -652,7 +672,16 @@ static int cmp_pointref(const void* a, const void* b)
 float orc_icp_run(const orc_kd* kd, const float* model, const float* data, int N,
                   float R[9], float t[3], int max_iter, float err_diff, int* iters_out)
 {
-	const int n = N, num = N; /* trim_fraction 0 */
+	return orc_icp_run_trim(kd, model, data, N, N, R, t, max_iter, err_diff, iters_out);
+}
+
+float orc_icp_run_trim(const orc_kd* kd, const float* model, const float* data, int N, int inliers,
+                       float R[9], float t[3], int max_iter, float err_diff, int* iters_out)
+{
+	/* num = the `inliers` nearest correspondences (jly_icp3d.hpp:191-199,236-252).  Deviation, documented:
+	 * the means are divided by num; the reference divides by n (jly_icp3d.hpp:259-260), which is only
+	 * correct for trim_fraction 0. */
+	const int n = N, num = inliers;
 	pointref_t* points = (pointref_t*)malloc(sizeof(pointref_t) * n);
 	float* p_m = (float*)malloc(sizeof(float) * 3 * num);
 	float* p_d = (float*)malloc(sizeof(float) * 3 * num);
@@ -687,7 +716,7 @@ float orc_icp_run(const orc_kd* kd, const float* model, const float* data, int N
 		}
 		if (err > 0 && err - err_new < err_diff * num) break;
 		err = err_new;
-		for (int a = 0; a < 3; a++) { mu_m[a] = mu_m[a] / (float)n; mu_d[a] = mu_d[a] / (float)n; }
+		for (int a = 0; a < 3; a++) { mu_m[a] = mu_m[a] / (float)num; mu_d[a] = mu_d[a] / (float)num; }
 		/* H = (p_d - mu_d)^T (p_m - mu_m), sequential float sums over the rows (matrix.cpp:296-299) */
 		float H[9] = { 0 };
 		for (int i = 0; i < 3; i++)
@@ -731,12 +760,20 @@ float orc_icp_run(const orc_kd* kd, const float* model, const float* data, int N
 int orc_register(const orc_dt* dt, const float* model, int M, const float* data, int N,
                  float mse_thresh, orc_result* out)
 {
+	return orc_register_trim(dt, model, M, data, N, mse_thresh, 0.f, out);
+}
+
+int orc_register_trim(const orc_dt* dt, const float* model, int M, const float* data, int N,
+                      float mse_thresh, float trim_fraction, orc_result* out)
+{
+	int inliers = (int)(N * (1 - trim_fraction));            /* jly_goicp.cpp:201 */
+	if (inliers < 1) inliers = 1;
 	float* norm = (float*)malloc(sizeof(float) * N);
 	float* rho = (float*)malloc(sizeof(float) * (size_t)ORC_MAXROTLEVEL * N);
 	float* prot = (float*)malloc(sizeof(float) * 3 * N);
 	orc_rot_radii(data, N, norm, rho);
 	orc_kd* kd = orc_kd_build(model, M);
-	const float sse_thresh = mse_thresh * N;                 /* :208, inlierNum = N */
+	const float sse_thresh = mse_thresh * inliers;           /* :208 */
 	const float icp_err_diff = mse_thresh / 10000;           /* :186 */
 	const float troot[4] = { -0.5f, -0.5f, -0.5f, 1.0f };    /* :50-53 */
 	memset(out, 0, sizeof(*out));
@@ -744,20 +781,16 @@ int orc_register(const orc_dt* dt, const float* model, int M, const float* data,
 	float optR[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, optT[3] = { 0, 0, 0 };
 	float optError;
 	{   /* :357-372 initial error */
-		float sse = 0;
-		for (int i = 0; i < N; i++) {
-			float d = orc_dt_distance(dt, data[3 * i], data[3 * i + 1], data[3 * i + 2]);
-			sse += d * d;
-		}
-		optError = sse;
+		const float I9[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Z3[3] = { 0, 0, 0 };
+		optError = orc_dt_sse_trim(dt, data, N, I9, Z3, inliers);
 	}
 	{   /* :375-391 initial ICP */
 		float R[9], t[3];
 		memcpy(R, optR, sizeof(R)); memcpy(t, optT, sizeof(t));
 		int it = 0;
-		orc_icp_run(kd, model, data, N, R, t, 10000, icp_err_diff, &it);
+		orc_icp_run_trim(kd, model, data, N, inliers, R, t, 10000, icp_err_diff, &it);
 		out->icp_runs++; out->icp_iters += it;
-		float e = orc_dt_sse(dt, data, N, R, t);
+		float e = orc_dt_sse_trim(dt, data, N, R, t, inliers);
 		if (e < optError) { optError = e; memcpy(optR, R, sizeof(R)); memcpy(optT, t, sizeof(t)); }
 	}
 
@@ -786,7 +819,7 @@ int orc_register(const orc_dt* dt, const float* model, int M, const float* data,
 			orc_rotate(R, data, N, prot);
 			float best[4] = { 0, 0, 0, 0 };
 			out->inner_calls++;
-			float ub = orc_inner_bnb(dt, prot, N, NULL, optError, sse_thresh, troot, best, &out->trans_pops, &out->cubes);
+			float ub = orc_inner_bnb_trim(dt, prot, N, NULL, inliers, optError, sse_thresh, troot, best, &out->trans_pops, &out->cubes);
 			if (ub < optError) {                              /* :495-544 */
 				optError = ub;
 				memcpy(optR, R, sizeof(R));
@@ -794,9 +827,9 @@ int orc_register(const orc_dt* dt, const float* model, int M, const float* data,
 				float Ri[9], ti[3];
 				memcpy(Ri, optR, sizeof(Ri)); memcpy(ti, optT, sizeof(ti));
 				int it = 0;
-				orc_icp_run(kd, model, data, N, Ri, ti, 10000, icp_err_diff, &it);
+				orc_icp_run_trim(kd, model, data, N, inliers, Ri, ti, 10000, icp_err_diff, &it);
 				out->icp_runs++; out->icp_iters += it;
-				float e = orc_dt_sse(dt, data, N, Ri, ti);
+				float e = orc_dt_sse_trim(dt, data, N, Ri, ti, inliers);
 				if (e < optError) { optError = e; memcpy(optR, Ri, sizeof(Ri)); memcpy(optT, ti, sizeof(ti)); }
 				if (optError < sse_thresh) { done = 1; break; }   /* :527 */
 				/* :533-543 drop queued nodes with lb >= optError (rebuild in pop order) */
@@ -811,7 +844,7 @@ int orc_register(const orc_dt* dt, const float* model, int M, const float* data,
 			}
 			int level = c.l < ORC_MAXROTLEVEL ? c.l : ORC_MAXROTLEVEL - 1; /* reference would overrun at l >= 20 */
 			out->inner_calls++;
-			float lb = orc_inner_bnb(dt, prot, N, rho + (size_t)level * N, optError, sse_thresh, troot, NULL, &out->trans_pops, &out->cubes);
+			float lb = orc_inner_bnb_trim(dt, prot, N, rho + (size_t)level * N, inliers, optError, sse_thresh, troot, NULL, &out->trans_pops, &out->cubes);
 			if (lb >= optError) continue;
 			c.ub = ub; c.lb = lb;
 			heap_push(&q, c);

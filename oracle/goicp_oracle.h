@@ -92,6 +92,11 @@ void  orc_kabsch_rotation(const float H[9], float R[9]);
 float orc_icp_run(const orc_kd* kd, const float* model_xyz, const float* data_xyz, int N,
                   float R[9], float t[3], int max_iter, float err_diff, int* iters);
 
+/* trimmed forms (see goicp_oracle.c for the one documented deviation: means over num, not n) */
+float orc_dt_sse_trim(const orc_dt* dt, const float* data_xyz, int N, const float R[9], const float t[3], int inliers);
+float orc_icp_run_trim(const orc_kd* kd, const float* model_xyz, const float* data_xyz, int N, int inliers,
+                       float R[9], float t[3], int max_iter, float err_diff, int* iters);
+
 typedef struct orc_result {
 	float R[9], t[3], sse;
 	long long rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters;
@@ -99,6 +104,9 @@ typedef struct orc_result {
 /* jly_goicp.cpp:342-585 (Initialize + OuterBnB).  data/model are already resized. */
 int   orc_register(const orc_dt* dt, const float* model_xyz, int M, const float* data_xyz, int N,
                    float mse_thresh, orc_result* out);
+
+int   orc_register_trim(const orc_dt* dt, const float* model_xyz, int M, const float* data_xyz, int N,
+                        float mse_thresh, float trim_fraction, orc_result* out);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,12 @@ def lib():
         L.orc_icp_run.restype = C.c_float
         L.orc_register.argtypes = [dp, fp, C.c_int, fp, C.c_int, C.c_float, C.POINTER(Result)]
         L.orc_register.restype = C.c_int
+        L.orc_register_trim.argtypes = [dp, fp, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.POINTER(Result)]
+        L.orc_register_trim.restype = C.c_int
+        L.orc_dt_sse_trim.argtypes = [dp, fp, C.c_int, fp, fp, C.c_int]
+        L.orc_dt_sse_trim.restype = C.c_float
+        L.orc_icp_run_trim.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, fp, fp, C.c_int, C.c_float, ip]
+        L.orc_icp_run_trim.restype = C.c_float
         _LIB = L
     return _LIB
 
@@ -254,6 +260,15 @@ class KdTree:
             idx[k], d2[k] = i.value, d.value
         return idx, d2
 
+    def icp_run_trim(self, data, inliers, R, t, max_iter=10000, err_diff=1e-7):
+        d, dp = _f(data)
+        R_ = np.array(R, dtype=np.float32).reshape(9).copy()
+        t_ = np.array(t, dtype=np.float32).reshape(3).copy()
+        it = C.c_int(0)
+        err = lib().orc_icp_run_trim(self.h, self.mp, dp, len(d), int(inliers), R_.ctypes.data_as(C.POINTER(C.c_float)),
+                                     t_.ctypes.data_as(C.POINTER(C.c_float)), int(max_iter), float(np.float32(err_diff)), C.byref(it))
+        return np.float32(err), R_.reshape(3, 3), t_, it.value
+
     def icp_run(self, data, R, t, max_iter=10000, err_diff=1e-7):
         d, dp = _f(data)
         R_ = np.array(R, dtype=np.float32).reshape(9).copy()
@@ -290,11 +305,18 @@ def kabsch_rotation(H):
     return R.reshape(3, 3)
 
 
-def register(dt, model, data, mse_thresh):
+def dt_sse_trim(dt, data, R, t, inliers):
+    d, dp = _f(data)
+    R_, Rp = _f(np.asarray(R).reshape(9))
+    t_, tp = _f(np.asarray(t).reshape(3))
+    return np.float32(lib().orc_dt_sse_trim(C.byref(dt.dt), dp, len(d), Rp, tp, int(inliers)))
+
+
+def register(dt, model, data, mse_thresh, trim_fraction=0.0):
     m, mp = _f(model)
     d, dp = _f(data)
     res = Result()
-    lib().orc_register(C.byref(dt.dt), mp, len(m), dp, len(d), np.float32(mse_thresh), C.byref(res))
+    lib().orc_register_trim(C.byref(dt.dt), mp, len(m), dp, len(d), float(np.float32(mse_thresh)), float(np.float32(trim_fraction)), C.byref(res))
     return {
         "R": np.array(res.R, dtype=np.float32).reshape(3, 3), "t": np.array(res.t, dtype=np.float32),
         "sse": np.float32(res.sse), "rot_pops": res.rot_pops, "trans_pops": res.trans_pops, "cubes": res.cubes,

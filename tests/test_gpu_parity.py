@@ -406,3 +406,62 @@ def test_invalid_arguments(pkg, bunny_model, bunny_data10):
     idx, d2 = reg.nn_query(bunny_model[:5])
     assert np.array_equal(idx, np.arange(5)) and np.all(d2 == 0)
     reg.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# trimming: GoICP::trimFraction > 0
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def reg10_trim(pkg, bunny_model, bunny_data10):
+    r = pkg.Registration(bunny_model, bunny_data10, 1e-3, trans_batch=1, wide_children=0, trim_fraction=0.1)
+    yield r
+    r.close()
+
+
+def test_trimmed_bounds_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_data10, rho10, reg10_trim):
+    """k-th-smallest selection on the GPU (radix select) vs sort-based selection in the oracle: rel 1e-4."""
+    k = int(len(bunny_data10) * (1 - np.float32(0.1)))
+    rng = np.random.default_rng(9)
+    R = pkg.fgoicp.rodrigues([0.3, -0.2, 0.9])
+    prot = oracle_mod.rotate(R, bunny_data10)
+    cubes = _cubes(rng, 40)
+    for level in (-1, 5):
+        ub, lb = reg10_trim.eval_bounds(R, cubes, level)
+        for i, c in enumerate(cubes):
+            oub, olb = oracle_mod.cube_bound_trim(oracle_dt_bunny, prot, rho10[level] if level >= 0 else None, c[:3], c[3], k)
+            assert abs(ub[i] - oub) <= 1e-4 * max(oub, 1e-3) and abs(lb[i] - olb) <= 1e-4 * max(olb, 1e-3)
+    I, Z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    assert abs(reg10_trim.compute_sse_error(I, Z) - oracle_mod.dt_sse_trim(oracle_dt_bunny, bunny_data10, I, Z, k)) <= 1e-4 * 100
+
+
+def test_trimmed_inner_bnb_golden(pkg, reg10_trim):
+    """The reference's own trimmed InnerBnB (trimFraction 0.1 set in the harness)."""
+    g = golden("inner_bnb_trim")
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for s in case["full"]:
+            v, best, cnt = reg10_trim.inner_bnb(R, s["level"], s["incumbent"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(cnt.trans_pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+            if s["level"] < 0:
+                assert np.array_equal(best, np.array(s["best"], np.float32))
+
+
+def test_trimmed_icp_vs_oracle(pkg, oracle_mod, bunny_model, bunny_data10, reg10_trim):
+    """Trimmed ICP (the num nearest correspondences; means over num -- the reference's /n is App. B-12,
+    so this one is checked against the oracle's definition: parity with the reference unpinned)."""
+    k = int(len(bunny_data10) * (1 - np.float32(0.1)))
+    kd = oracle_mod.KdTree(bunny_model)
+    for iters in (1, 3, 10):
+        err, R, t = pkg.IterativeClosestPoint3D(reg10_trim, iters, 1e-9).run()
+        oerr, oR, ot, _ = kd.icp_run_trim(bunny_data10, k, np.eye(3), np.zeros(3), iters, 1e-9)
+        assert abs(err - oerr) <= 1e-3 * oerr and np.abs(R - oR).max() <= 2e-4 and np.abs(t - ot).max() <= 2e-4
+
+
+def test_trimmed_e2e_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bunny_data10):
+    eng = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, trim_fraction=0.1, trans_batch=1, wide_children=0)
+    eng.run()
+    o = oracle_mod.register(oracle_dt_bunny, bunny_model, bunny_data10, 1e-3, trim_fraction=0.1)
+    assert rot_angle(eng.optR, o["R"]) <= 2e-3 and np.linalg.norm(eng.optT - o["t"]) <= 2e-3
+    assert abs(eng.get_best_error() - o["sse"]) <= 0.02 * o["sse"]
+    assert eng.get_best_error() < eng.registration.params.mse_threshold * int(len(bunny_data10) * 0.9) * 1.0001

@@ -3,6 +3,8 @@
  (2) the CPU oracle (oracle/goicp_oracle.c) on the same seeded inputs.
 Tolerances are SURVEY.md 8(c)'s and are written next to each assertion.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -465,3 +467,51 @@ def test_trimmed_e2e_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bu
     assert rot_angle(eng.optR, o["R"]) <= 2e-3 and np.linalg.norm(eng.optT - o["t"]) <= 2e-3
     assert abs(eng.get_best_error() - o["sse"]) <= 0.02 * o["sse"]
     assert eng.get_best_error() < eng.registration.params.mse_threshold * int(len(bunny_data10) * 0.9) * 1.0001
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs[0]: plain ICP (modes 0-2), step API, bunny-scale clouds
+# ----------------------------------------------------------------------------------------------
+def test_plain_icp_steps_vs_oracle(pkg, oracle_mod, s1):
+    """ICP::kdTreeGPUStep x 20 on a 40 000 / 40 000 pair (the bun000/bun045 PLYs of bunny_icp.toml cannot
+    travel; S1 is their synthetic twin): every step = one oracle ICP iteration with fresh
+    means from the accumulated pose.  1e-4 abs on R, t after 20 steps."""
+    target, source, Rgt, tgt = s1
+    # source = the target under a small known motion: plain ICP converges without the global search
+    src = (target @ pkg.fgoicp.rodrigues([0.05, -0.04, 0.03]).astype(np.float32) + np.float32(0.01)).astype(np.float32)
+    reg = pkg.Registration(target, src, 1e-5, dt_size=128)
+    kd = oracle_mod.KdTree(target)
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    for _ in range(20):
+        snap = reg.icp_step()
+        _, R, t, _ = kd.icp_run(src, R, t, 1, -1e30)
+    assert np.abs(np.array(snap.curR, np.float32).reshape(3, 3) - R).max() <= 1e-4
+    assert np.abs(np.array(snap.curT, np.float32) - t).max() <= 1e-4
+    assert snap.best_sse < 1e-3 * len(src)                       # converged onto the target
+    reg.close()
+
+
+def test_cli_end_to_end(pkg, tmp_path):
+    """goicp_cli with a reference-style .toml (TXT clouds, relative paths, output.toml + viz.ply)."""
+    import subprocess
+    from conftest import ROOT
+    for name in ("model_rand", "data_rand"):
+        pts = cloud(name)
+        with open(tmp_path / (name + ".txt"), "w") as f:
+            f.write("%d\n" % len(pts))
+            for q in pts:
+                f.write("%.9g %.9g %.9g\n" % tuple(q))
+    (tmp_path / "cfg.toml").write_text(
+        '[info]\ndescription = "cli test"\n[io]\ntarget = "model_rand.txt"\nsource = "data_rand.txt"\n'
+        'output = "%s"\nvisualization = "%s"\n[params]\nmode = 4\nsubsample = 1.0\nmse_threshold = 1e-3\nresize = 1.0\n'
+        % (tmp_path / "output.toml", tmp_path / "viz.ply"))
+    exe = os.path.join(ROOT, "cuda-go-icp_amd", "goicp_cli")
+    out = subprocess.run([exe, str(tmp_path / "cfg.toml")], check=True, capture_output=True, text=True, timeout=120).stdout
+    g = golden("e2e_rand100")
+    assert "Optimal Rotation Matrix" in out and "Optimal Translation Vector" in out
+    txt = (tmp_path / "output.toml").read_text()
+    sse = float([l for l in txt.splitlines() if l.startswith("sse =")][0].split("=")[1])
+    assert sse <= 1.02 * g["sse"]
+    assert pkg.load_cloud(tmp_path / "viz.ply").shape == (200, 3)
+    bad = subprocess.run([exe, str(tmp_path / "missing.toml")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "error" in bad.stderr.lower()

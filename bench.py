@@ -227,6 +227,18 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
+        # ---- the same batch through the host-pointer entry point (PCIe-inclusive; never `value`) ----
+        h_ub, h_lb = np.empty(Bc, np.float32), np.empty(Bc, np.float32)
+        cube_arr = (B.CCube * Bc).from_buffer_copy(recs.tobytes())
+        fpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        B.check(lib.goicp_eval_bounds_batch(h, fpp(rots.reshape(-1)), len(rots), cube_arr, Bc, fpp(h_ub), fpp(h_lb)))
+        t1 = time.perf_counter()
+        for _ in range(5):
+            B.check(lib.goicp_eval_bounds_batch(h, fpp(rots.reshape(-1)), len(rots), cube_arr, Bc, fpp(h_ub), fpp(h_lb)))
+        host_ms = (time.perf_counter() - t1) / 5 * 1e3
+        roofline["host_pointer_call_ms"] = round(host_ms, 4)
+        roofline["host_pointer_cube_bounds_per_s"] = round(Bc / (host_ms * 1e-3), 1)
+        assert np.array_equal(h_ub, d_ub.cpu().numpy()), "host-pointer and device-pointer entry points disagree"
         # ---- ICP iterations/s ----
         icp = None
         if not args.no_icp:

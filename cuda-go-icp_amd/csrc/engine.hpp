@@ -170,6 +170,6 @@ struct KdHost {
 	int K = 1, L = 64;
 };
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
-void rodrigues(float v1, float v2, float v3, float R[9]);   // jly_goicp.cpp:449-467
+void rodrigues(float ax, float ay, float az, float R[9]);   // jly_goicp.cpp:449-467
 
 }  // namespace goicp

@@ -86,23 +86,22 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 	}
 }
 
-void rodrigues(float v1, float v2, float v3, float R[9])
+void rodrigues(float ax, float ay, float az, float R[9])
 {
-	// angle-axis cube centre -> rotation matrix, float arithmetic in the order of jly_goicp.cpp:449-467
-	float t = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
-	if (!(t > 0.f)) {
-		const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-		std::memcpy(R, I, sizeof(I));
+	// angle-axis vector (a rotation-cube centre) -> rotation matrix.  Float arithmetic with the same
+	// operation order as GoICP::OuterBnB (jly_goicp.cpp:449-467), so R is bit-identical to the CPU path's.
+	const float theta = std::sqrt(ax * ax + ay * ay + az * az);
+	if (!(theta > 0.f)) {
+		for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.f : 0.f;
 		return;
 	}
-	v1 /= t; v2 /= t; v3 /= t;
-	float ct = std::cos(t), ct2 = 1 - ct, st = std::sin(t);
-	float tmp121 = v1 * v2 * ct2, tmp122 = v3 * st;
-	float tmp131 = v1 * v3 * ct2, tmp132 = v2 * st;
-	float tmp231 = v2 * v3 * ct2, tmp232 = v1 * st;
-	R[0] = ct + v1 * v1 * ct2; R[1] = tmp121 - tmp122;    R[2] = tmp131 + tmp132;
-	R[3] = tmp121 + tmp122;    R[4] = ct + v2 * v2 * ct2; R[5] = tmp231 - tmp232;
-	R[6] = tmp131 - tmp132;    R[7] = tmp231 + tmp232;    R[8] = ct + v3 * v3 * ct2;
+	const float ux = ax / theta, uy = ay / theta, uz = az / theta;   // unit axis
+	const float c = std::cos(theta), omc = 1 - c, sn = std::sin(theta);
+	const float xy = ux * uy * omc, xz = ux * uz * omc, yz = uy * uz * omc;
+	const float zs = uz * sn, ys = uy * sn, xs = ux * sn;
+	R[0] = c + ux * ux * omc; R[1] = xy - zs;           R[2] = xz + ys;
+	R[3] = xy + zs;           R[4] = c + uy * uy * omc; R[5] = yz - xs;
+	R[6] = xz - ys;           R[7] = yz + xs;           R[8] = c + uz * uz * omc;
 }
 
 }  // namespace goicp

@@ -274,22 +274,21 @@ void orc_rot_radii(const float* d, int N, float* norm, float* rho)
 	}
 }
 
-void orc_rodrigues(float v1, float v2, float v3, float R[9])
+void orc_rodrigues(float ax, float ay, float az, float R[9])
 {
-	/* jly_goicp.cpp:449-467 */
-	float t = sqrtf(v1 * v1 + v2 * v2 + v3 * v3);
-	if (!(t > 0)) {
-		R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+	/* jly_goicp.cpp:449-467: angle-axis -> matrix, float, same operation order */
+	float theta = sqrtf(ax * ax + ay * ay + az * az);
+	if (!(theta > 0)) {
+		for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.f : 0.f;
 		return;
 	}
-	v1 /= t; v2 /= t; v3 /= t;
-	float ct = cosf(t), ct2 = 1 - ct, st = sinf(t);
-	float tmp121 = v1 * v2 * ct2, tmp122 = v3 * st;
-	float tmp131 = v1 * v3 * ct2, tmp132 = v2 * st;
-	float tmp231 = v2 * v3 * ct2, tmp232 = v1 * st;
-	R[0] = ct + v1 * v1 * ct2; R[1] = tmp121 - tmp122;    R[2] = tmp131 + tmp132;
-	R[3] = tmp121 + tmp122;    R[4] = ct + v2 * v2 * ct2; R[5] = tmp231 - tmp232;
-	R[6] = tmp131 - tmp132;    R[7] = tmp231 + tmp232;    R[8] = ct + v3 * v3 * ct2;
+	float ux = ax / theta, uy = ay / theta, uz = az / theta;
+	float c = cosf(theta), omc = 1 - c, sn = sinf(theta);
+	float xy = ux * uy * omc, xz = ux * uz * omc, yz = uy * uz * omc;
+	float zs = uz * sn, ys = uy * sn, xs = ux * sn;
+	R[0] = c + ux * ux * omc; R[1] = xy - zs;           R[2] = xz + ys;
+	R[3] = xy + zs;           R[4] = c + uy * uy * omc; R[5] = yz - xs;
+	R[6] = xz - ys;           R[7] = yz + xs;           R[8] = c + uz * uz * omc;
 }
 
 void orc_rotate(const float R[9], const float* d, int N, float* o)

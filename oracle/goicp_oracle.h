@@ -49,7 +49,7 @@ void  orc_rot_radii(const float* data_xyz, int N, float* norm, float* rho);
 /* the per-level coefficient 2*sin(min(sqrt3*sigma_l, pi)/2) as a float */
 float orc_rot_coeff(int level);
 /* jly_goicp.cpp:449-467 */
-void  orc_rodrigues(float v1, float v2, float v3, float R[9]);
+void  orc_rodrigues(float ax, float ay, float az, float R[9]);
 /* jly_goicp.cpp:470-476 */
 void  orc_rotate(const float R[9], const float* data_xyz, int N, float* out_xyz);
 

@@ -126,19 +126,17 @@ static int cmd_e2e(int argc, char** argv)
 // ---------------------------------------------------------------- unit fixtures
 static void rodrigues(const float v[3], float R[9])
 {
-	// harness-side rotation set-up, same formula family as src/goicp/jly_goicp.cpp:449-467;
-	// the consumer of the fixture receives R itself, so only R·p must agree.
-	float v1 = v[0], v2 = v[1], v3 = v[2];
-	float t = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
-	if (t <= 0) { float I[9] = {1,0,0,0,1,0,0,0,1}; memcpy(R, I, sizeof(I)); return; }
-	v1 /= t; v2 /= t; v3 /= t;
-	float ct = cos(t), ct2 = 1 - ct, st = sin(t);
-	float tmp121 = v1 * v2 * ct2, tmp122 = v3 * st;
-	float tmp131 = v1 * v3 * ct2, tmp132 = v2 * st;
-	float tmp231 = v2 * v3 * ct2, tmp232 = v1 * st;
-	R[0] = ct + v1 * v1 * ct2; R[1] = tmp121 - tmp122;   R[2] = tmp131 + tmp132;
-	R[3] = tmp121 + tmp122;    R[4] = ct + v2 * v2 * ct2; R[5] = tmp231 - tmp232;
-	R[6] = tmp131 - tmp132;    R[7] = tmp231 + tmp232;   R[8] = ct + v3 * v3 * ct2;
+	// harness-side rotation set-up (angle-axis -> matrix); the consumer of a fixture receives R itself,
+	// so only R*p has to agree with the reference.
+	float theta = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+	if (theta <= 0) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.f : 0.f; return; }
+	float ux = v[0] / theta, uy = v[1] / theta, uz = v[2] / theta;
+	float c = cos(theta), omc = 1 - c, sn = sin(theta);
+	float xy = ux * uy * omc, xz = ux * uz * omc, yz = uy * uz * omc;
+	float zs = uz * sn, ys = uy * sn, xs = ux * sn;
+	R[0] = c + ux * ux * omc; R[1] = xy - zs;           R[2] = xz + ys;
+	R[3] = xy + zs;           R[4] = c + uy * uy * omc; R[5] = yz - xs;
+	R[6] = xz - ys;           R[7] = yz + xs;           R[8] = c + uz * uz * omc;
 }
 
 static int cmd_units(int argc, char** argv)

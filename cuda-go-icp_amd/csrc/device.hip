@@ -454,16 +454,20 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 constexpr int kIcpThreads = 256;     // 4 wavefronts per workgroup
 constexpr int kIcpQueriesPerWave = 2;
 
-struct NnResult { float best; int idx; int slot; };
+struct NnResult { float best; int idx; int slot; float mx, my, mz; };
+struct Box6 { float lox, loy, loz, hix, hiy, hiz; };   // one child box per lane
 
-__device__ __forceinline__ float child_box_lb(const float* __restrict__ g, int lane, float qx, float qy, float qz)
+__device__ __forceinline__ Box6 load_child_box(const float* __restrict__ g, int lane)
 {
 	// group record: lo_x[64] lo_y[64] lo_z[64] hi_x[64] hi_y[64] hi_z[64]
-	const float lox = g[lane], loy = g[64 + lane], loz = g[128 + lane];
-	const float hix = g[192 + lane], hiy = g[256 + lane], hiz = g[320 + lane];
-	const float ex = fmaxf(fmaxf(lox - qx, qx - hix), 0.f);
-	const float ey = fmaxf(fmaxf(loy - qy, qy - hiy), 0.f);
-	const float ez = fmaxf(fmaxf(loz - qz, qz - hiz), 0.f);
+	return Box6{g[lane], g[64 + lane], g[128 + lane], g[192 + lane], g[256 + lane], g[320 + lane]};
+}
+
+__device__ __forceinline__ float box_lb(const Box6& b, float qx, float qy, float qz)
+{
+	const float ex = fmaxf(fmaxf(b.lox - qx, qx - b.hix), 0.f);
+	const float ey = fmaxf(fmaxf(b.loy - qy, qy - b.hiy), 0.f);
+	const float ez = fmaxf(fmaxf(b.loz - qz, qz - b.hiz), 0.f);
 	float d = ex * ex;         // same accumulation order as the point distance
 	d += ey * ey;
 	d += ez * ez;
@@ -488,8 +492,9 @@ __device__ __forceinline__ int nearest_pending(float lb, unsigned long long pend
 __device__ __forceinline__ void scan_leaf(const KdDesc& kd, int leaf, int lane, float qx, float qy, float qz, NnResult& r)
 {
 	float d = INFINITY; int id = INT_MAX;
+	float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
 	if (lane < kLeafSlots) {
-		const float4 p = kd.pts[leaf * kLeafSlots + lane];
+		p = kd.pts[leaf * kLeafSlots + lane];
 		// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
 		const float d0 = qx - p.x, d1 = qy - p.y, d2 = qz - p.z;
 		d = d0 * d0;
@@ -504,31 +509,41 @@ __device__ __forceinline__ void scan_leaf(const KdDesc& kd, int leaf, int lane, 
 		better &= better - 1;
 		const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), c));
 		const int iv = __builtin_amdgcn_readlane(id, c);
-		if (dv < r.best || (dv == r.best && iv < r.idx)) { r.best = dv; r.idx = iv; r.slot = leaf * kLeafSlots + c; }
+		if (dv < r.best || (dv == r.best && iv < r.idx)) {
+			r.best = dv; r.idx = iv; r.slot = leaf * kLeafSlots + c;
+			r.mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), c));   // the matched point rides along
+			r.my = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), c));
+			r.mz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), c));
+		}
 	}
 }
 
 template <int K, int LVL>
-__device__ __forceinline__ void visit_group(const KdDesc& kd, int group, int lane, float qx, float qy, float qz, NnResult& r)
+__device__ __forceinline__ void visit_group(const KdDesc& kd, int group, const Box6& mybox, int lane, float qx, float qy, float qz, NnResult& r)
 {
-	const float lb = child_box_lb(kd.boxes[LVL] + (size_t)group * 384, lane, qx, qy, qz);
+	const float lb = box_lb(mybox, qx, qy, qz);
 	unsigned long long pending = __ballot(lb <= r.best);
 	while (pending) {
 		const int c = nearest_pending(lb, pending);                      // nearest pending child
 		pending &= ~(1ull << c);
 		const int child = group * 64 + c;
 		if (LVL == K - 1) scan_leaf(kd, child, lane, qx, qy, qz, r);
-		else visit_group<K, (LVL + 1 < K ? LVL + 1 : LVL)>(kd, child, lane, qx, qy, qz, r);
+		else {
+			constexpr int NL = LVL + 1 < K ? LVL + 1 : LVL;
+			const Box6 cb = load_child_box(kd.boxes[NL] + (size_t)child * 384, lane);
+			visit_group<K, NL>(kd, child, cb, lane, qx, qy, qz, r);
+		}
 		pending &= __ballot(lb <= r.best);                              // re-filter with the improved bound
 	}
 }
 
-// exact 1-NN of one query by the whole wavefront (all lanes hold the same q and get the same result)
+// exact 1-NN of one query by the whole wavefront (all lanes hold the same q and get the same result);
+// rootbox = this lane's child box of the root group, loaded once per wavefront
 template <int K>
-__device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, int lane, float qx, float qy, float qz, float bound)
+__device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, const Box6& rootbox, int lane, float qx, float qy, float qz, float bound)
 {
-	NnResult r{bound, INT_MAX, 0};
-	visit_group<K, 0>(kd, 0, lane, qx, qy, qz, r);
+	NnResult r{bound, INT_MAX, 0, 0.f, 0.f, 0.f};
+	visit_group<K, 0>(kd, 0, rootbox, lane, qx, qy, qz, r);
 	return r;
 }
 
@@ -550,6 +565,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __r
 	if (st->converged) return;                                          // loop already finished: queued launches drain
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int w = blockIdx.x * (kIcpThreads / 64) + wave;               // global wavefront index
+	const Box6 rootbox = load_child_box(kd.boxes[0], lane);
 	float acc[kIcpAcc];
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
@@ -561,10 +577,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __r
 		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
 		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
 		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-		const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
-		const float4 m = kd.pts[r.slot];
+		const NnResult r = wave_nearest<K>(kd, rootbox, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
 		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
-		const float bx = m.x - st->cm[0], by = m.y - st->cm[1], bz = m.z - st->cm[2];
+		const float bx = r.mx - st->cm[0], by = r.my - st->cm[1], bz = r.mz - st->cm[2];
 		acc[0] += ax; acc[1] += ay; acc[2] += az;
 		acc[3] += bx; acc[4] += by; acc[5] += bz;
 		acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
@@ -598,6 +613,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const float4* __res
 	if (st->converged) return;
 	const int lane = threadIdx.x & 63;
 	const int w = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);
+	const Box6 rootbox = load_child_box(kd.boxes[0], lane);
 	for (int j = 0; j < kIcpQueriesPerWave; j++) {
 		const int i = w * kIcpQueriesPerWave + j;
 		if (i >= N) break;
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const float4* __res
 		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
 		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
 		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-		const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
+		const NnResult r = wave_nearest<K>(kd, rootbox, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
 		if (lane == 0) { nn_d2[i] = r.best; nn_slot[i] = r.slot; }
 	}
 }
@@ -923,7 +939,7 @@ __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __re
 	const int i = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);   // one wavefront per query
 	if (i >= n) return;
 	const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-	const NnResult r = wave_nearest<K>(kd, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
+	const NnResult r = wave_nearest<K>(kd, load_child_box(kd.boxes[0], lane), lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
 	if (lane == 0) { idx[i] = r.idx; d2[i] = r.best; }
 }
 

@@ -76,6 +76,10 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	if (!target || !source || M == 0 || N == 0) throw std::invalid_argument("goicp: empty target or source cloud");
 	if (M > (size_t)INT32_MAX / 8 || N > (size_t)INT32_MAX / 8) throw std::invalid_argument("goicp: cloud too large");
 	if (p_.dt_size < 8 || p_.dt_size > 640) throw std::invalid_argument("goicp: dt_size must be in [8,640]");
+	if (!(p_.dt_expand >= 1.0) || !(p_.dt_expand <= 64.0)) throw std::invalid_argument("goicp: dt_expand must be in [1,64]");
+	if (!(p_.mse_threshold > 0.f)) p_.mse_threshold = 1e-10f;             // the reference clamps the same way (src/common.cpp:64)
+	for (size_t i = 0; i < 3 * M; i++) if (!std::isfinite(target[i])) throw std::invalid_argument("goicp: non-finite coordinate in the target cloud");
+	for (size_t i = 0; i < 3 * N; i++) if (!std::isfinite(source[i])) throw std::invalid_argument("goicp: non-finite coordinate in the source cloud");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		throw std::runtime_error("goicp: no HIP device available (this engine has no CPU fallback)");

@@ -56,11 +56,15 @@ def test_dt_grid_vs_reference_voxels(reg10):
     assert np.all(mine <= ref + 1e-7) and np.max(ref - mine) <= 0.35 * vox
 
 
-@pytest.mark.parametrize("layout", [0, 1])
-def test_dt_layouts_agree(pkg, bunny_model, bunny_data10, oracle_mod, layout):
-    r = pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_layout=layout, dt_size=96)
-    dt = oracle_mod.DistanceTransform(bunny_model, 96, 2.0)
+@pytest.mark.parametrize("layout,V", [(0, 96), (1, 96), (1, 50), (0, 33)])
+def test_dt_layouts_agree(pkg, bunny_model, bunny_data10, oracle_mod, layout, V):
+    """both layouts, including grid sides that are not a multiple of the 4-voxel brick"""
+    r = pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_layout=layout, dt_size=V)
+    dt = oracle_mod.DistanceTransform(bunny_model, V, 2.0)
     assert np.array_equal(r.dt_download(), dt.grid())
+    ub, lb = r.eval_bounds(np.eye(3), np.array([[0.1, -0.2, 0.05, 0.25]], np.float32), -1)
+    oub, olb = oracle_mod.cube_bound(dt, bunny_data10, None, [0.1, -0.2, 0.05], 0.25)
+    assert abs(ub[0] - oub) <= 1e-4 * oub and abs(lb[0] - olb) <= 1e-4 * max(olb, 1e-3)
     r.close()
 
 
@@ -402,6 +406,14 @@ def test_invalid_arguments(pkg, bunny_model, bunny_data10):
         pkg.Registration(np.zeros((0, 3), np.float32), bunny_data10)
     with pytest.raises(pkg.GoicpError):
         pkg.Registration(bunny_model, bunny_data10, dt_size=4)
+    bad = bunny_data10.copy(); bad[7, 1] = np.nan
+    with pytest.raises(pkg.GoicpError) as e:
+        pkg.Registration(bunny_model, bad)
+    assert e.value.code == -1 and "non-finite" in str(e.value)
+    with pytest.raises(pkg.GoicpError):
+        pkg.Registration(np.tile(bunny_model[:1], (10, 1)), bunny_data10)            # zero-extent target
+    with pytest.raises(pkg.GoicpError):
+        pkg.Registration(bunny_model, bunny_data10, trim_fraction=1.0)
     reg = pkg.Registration(bunny_model[:5], bunny_data10[:1], 1e-3, dt_size=32)     # tiny clouds are legal
     ub, lb = reg.eval_bounds(np.eye(3), np.array([[0, 0, 0, 0.5]], np.float32), -1)
     assert np.isfinite(ub[0]) and lb[0] <= ub[0]

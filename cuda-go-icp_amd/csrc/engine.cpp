@@ -497,6 +497,8 @@ void Engine::icp_step()
 // ------------------------------------------------------------------------------------------------
 void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
 {
+	const double t_begin = now_ms();
+	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
 	const int K = std::max(1, p_.trans_batch);
 	const size_t nrot = rots.size();
 	for (auto* s : searches)
@@ -612,6 +614,8 @@ void Engine::adopt(float err, const float R[9], const float t[3])
 
 float Engine::icp_from(float R[9], float t[3])
 {
+	const double t0 = now_ms();
+	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{icp_ms_, t0};
 	// GoICP::ICP (jly_goicp.cpp:93-132): ICP3D::Run, then re-score with the DT
 	int it = 0;
 	icp_run(R, t, p_.icp_max_iter, icp_err_diff_, &it);
@@ -638,6 +642,7 @@ void Engine::register_begin()
 {
 	cancel_.store(false);
 	early_exit_ = converged_ = false;
+	icp_ms_ = 0;
 	cnt_ = Counters{};
 	while (!queue_.empty()) queue_.pop();
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -651,6 +656,7 @@ void Engine::register_begin()
 	if (e < opt_err_) adopt(e, R, t);
 	std::memcpy(curR_, optR_, sizeof(optR_)); std::memcpy(curT_, optT_, sizeof(optT_));
 	if (p_.verbose) std::fprintf(stderr, "[goicp] init error %.6g (after ICP)\n", opt_err_);
+	bnb_ms_ = 0;
 
 	Node root{(float)-kPI, (float)-kPI, (float)-kPI, (float)(2 * kPI), 0.f, 0.f, 0};   // jly_goicp.cpp:44-48
 	if (world_ <= 1) {
@@ -807,6 +813,9 @@ void Engine::run()
 		if (st.finished) break;
 	}
 	register_ms_ = now_ms() - t0;
+	if (p_.verbose)
+		std::fprintf(stderr, "[goicp] register %.2f ms: inner BnB rounds %.2f ms (%lld launches), ICP + DT re-score %.2f ms (%lld passes)\n",
+		             register_ms_, bnb_ms_, cnt_.bounds_launches, icp_ms_, cnt_.icp_iters);
 	register_end();
 }
 

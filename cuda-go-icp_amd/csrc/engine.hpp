@@ -20,9 +20,9 @@ struct Params {
 	float mse_threshold = 1e-3f;  // Config::mse_threshold (common.cpp:62)
 	int dt_layout = 1;            // 0 linear, 1 bricked 4x4x4
 	int device = -1;              // -1: current HIP device
-	int trans_batch = 16;         // translation nodes expanded per inner search per launch (1 = reference order)
+	int trans_batch = 32;         // translation nodes expanded per inner search per launch (1 = reference order)
 	int wide_children = 1;        // run the rotation children's inner searches concurrently (0 = reference order)
-	int rot_batch = 4;            // rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches)
+	int rot_batch = 8;            // rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches)
 	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
 	int verbose = 0;
 	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
@@ -158,7 +158,7 @@ private:
 	std::atomic<bool> cancel_{false};
 	std::mutex mtx_;
 	Result snap_{};
-	double dt_build_ms_ = 0, register_ms_ = 0;
+	double dt_build_ms_ = 0, register_ms_ = 0, bnb_ms_ = 0, icp_ms_ = 0;
 	// icp_step state
 	float stepR_[9], stepT_[3];
 };

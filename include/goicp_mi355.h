@@ -96,7 +96,7 @@ typedef struct goicp_params {
 	int32_t icp_max_iter;    /* reference 10000 (src/goicp/jly_icp3d.hpp:114) */
 	int32_t verbose;
 	int32_t morton_sort;     /* 1: source cloud kept in Morton order on the device */
-	int32_t rot_batch;       /* rotation nodes expanded per round when wide_children (default 4) */
+	int32_t rot_batch;       /* rotation nodes expanded per round when wide_children (default 8) */
 	float trim_fraction;     /* GoICP::trimFraction (src/goicp/jly_goicp.h:116): fraction of the largest residuals ignored; reference 0 */
 } goicp_params;
 

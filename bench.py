@@ -227,6 +227,16 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
+        # ---- what this GPU's HBM actually streams (device-to-device copy of 2 GiB, read + write counted) ----
+        a_ = torch.empty(1 << 29, dtype=torch.float32, device=dev); b_ = torch.empty_like(a_)
+        b_.copy_(a_); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b_.copy_(a_)
+        e1.record(); torch.cuda.synchronize()
+        roofline["hbm_copy_probe_GBs"] = round(5 * 2 * a_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a_, b_
         # ---- the same batch through the host-pointer entry point (PCIe-inclusive; never `value`) ----
         h_ub, h_lb = np.empty(Bc, np.float32), np.empty(Bc, np.float32)
         cube_arr = (B.CCube * Bc).from_buffer_copy(recs.tobytes())

@@ -391,12 +391,22 @@ void Engine::nn_query(const float* q, size_t n, int32_t* idx, float* d2)
 
 void Engine::source_transformed(const float R[9], const float t[3], float* out)
 {
+	// rigid transform apply on the device (kernTransform, src/goicp_kernel.cu:16-22), then back to the
+	// caller's point order
+	float4* d_tmp = nullptr;
+	HIPCHK(hipMalloc(&d_tmp, sizeof(float4) * N_));
+	HIPCHK(hipMemcpyAsync(d_tmp, d_src_, sizeof(float4) * N_, hipMemcpyDeviceToDevice, stream_));
+	Pose pose;
+	std::memcpy(pose.R, R, sizeof(pose.R));
+	std::memcpy(pose.t, t, sizeof(pose.t));
+	HIPCHK(launch_transform(d_tmp, (int)N_, pose, stream_));
+	std::vector<float> h(4 * N_);
+	HIPCHK(hipMemcpyAsync(h.data(), d_tmp, sizeof(float4) * N_, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	HIPCHK(hipFree(d_tmp));
 	for (size_t i = 0; i < N_; i++) {
-		const float* p = &h_src_sorted_[4 * i];
 		float* o = out + 3 * (size_t)src_perm_[i];
-		o[0] = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
-		o[1] = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
-		o[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+		o[0] = h[4 * i]; o[1] = h[4 * i + 1]; o[2] = h[4 * i + 2];
 	}
 }
 

@@ -110,6 +110,7 @@ public:
 private:
 	struct InnerSearch;
 	void ensure_batch(size_t B, size_t K);
+	void ensure_stage(int k, size_t B);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
 	void process_parents(const std::vector<Node>& parents);
 	void adopt(float err, const float R[9], const float t[3]);
@@ -142,6 +143,11 @@ private:
 	Rot9* d_rots_ = nullptr; Rot9* h_rots_ = nullptr;
 	float* d_ub_ = nullptr; float* d_lb_ = nullptr; float* h_ub_ = nullptr; float* h_lb_ = nullptr;
 	float* d_scratch_ = nullptr;
+	struct Stage {   // per-group staging of the pipelined inner-BnB rounds
+		CubeRec* d_cubes = nullptr; CubeRec* h_cubes = nullptr;
+		float* d_ub = nullptr; float* d_lb = nullptr; float* h_ub = nullptr; float* h_lb = nullptr;
+		size_t cap = 0, B = 0; hipEvent_t ev = nullptr;
+	} stage_[2];
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
 	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only

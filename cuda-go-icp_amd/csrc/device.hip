@@ -523,8 +523,13 @@ __device__ __forceinline__ void visit_group(const KdDesc& kd, int group, const B
 {
 	const float lb = box_lb(mybox, qx, qy, qz);
 	unsigned long long pending = __ballot(lb <= r.best);
+	bool first = true;
 	while (pending) {
-		const int c = nearest_pending(lb, pending);                      // nearest pending child
+		// the nearest pending child first (it usually holds the neighbour and shrinks the bound), the rest in
+		// index order: measured 93 / 66 us per pass (identity / converged pose) against 122 / 73 us for
+		// always-nearest and 109 / 82 us for pure index order -- the pass is instruction-issue bound
+		const int c = first ? nearest_pending(lb, pending) : (__ffsll((long long)pending) - 1);
+		first = false;
 		pending &= ~(1ull << c);
 		const int child = group * 64 + c;
 		if (LVL == K - 1) scan_leaf(kd, child, lane, qx, qy, qz, r);

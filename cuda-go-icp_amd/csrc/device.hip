@@ -4,16 +4,19 @@
 // src/goicp/jly_goicp.cpp / jly_3ddt.cpp / jly_icp3d.hpp; only the order of the sums differs.
 //
 // Kernels
-//   bounds_kernel      (a) BnB cube bounds: rotate + translate the source cloud, gather the 3-D
-//                      Euclidean distance transform, subtract uncertainty radii, sum of squares.
-//                      HBM/L2-bound gather, 16 B (ub pass) / 20 B (lb pass) algorithmic per point.
-//   bounds_finalize    fixed-order sum of the per-chunk partials (deterministic, no float atomics)
-//   icp_pass_kernel    (b) one ICP correspondence pass: transform, exact 1-NN in the implicit k-d
-//                      tree (stackless traversal), pivoted centroid/covariance sums, wave64 reductions
-//   icp_finalize       fixed-order double-precision sum of the per-wave partials
-//   transform_kernel   in-place rigid transform apply
-//   nn_query_kernel    k-d tree 1-NN operator for arbitrary queries
-//   dt_*               exact Euclidean DT build (seed, three separable min-plus passes, sqrt/scale)
+//   bounds_kernel        (a) BnB cube bounds: rotate + translate the source cloud, gather the 3-D
+//                        Euclidean distance transform, subtract uncertainty radii, sum of squares.
+//                        16 B (ub pass) / 20 B (lb pass) algorithmic per point; sibling fast path.
+//   bounds_finalize      fixed-order sum of the per-chunk partials (deterministic, no float atomics)
+//   bounds_trim_kernel   trimmed form: exact k-th smallest residual per cube by radix select
+//   icp_pass_kernel      (b) one ICP correspondence pass: transform, exact 1-NN (one wavefront per
+//                        query over a 64-ary box hierarchy, DT-seeded bound), pivoted sums
+//   icp_finalize_update  fixed-order double-precision reduction + the rest of the ICP loop body
+//                        (convergence test, SVD, pose update) on the device-resident state
+//   icp_nn/select/accum  trimmed ICP: NN of every point, radix select of the num nearest, sums
+//   transform_kernel     rigid transform apply
+//   nn_query_kernel      1-NN operator for arbitrary queries
+//   dt_*                 exact Euclidean DT build (seed, three separable min-plus passes, sqrt/scale)
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cmath>
@@ -443,7 +446,7 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 //   * children are entered nearest-box-first, and only while their box is within the best
 //     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes and min-reduced
 //     with DPP shuffles; after every improvement the pending ballots are re-filtered;
-//   * the search starts from the upper bound (DT(q) + 2.5 voxel)^2 read from the distance
+//   * the search starts from the upper bound (DT(q) + 1.75 voxel)^2 read from the distance
 //     transform the engine already holds, so queries far from the surface prune as well as
 //     near ones;
 //   * all control flow is wave-uniform: no divergence, no per-lane stack, no tail lanes.
@@ -553,11 +556,11 @@ __device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, const Box6& r
 }
 
 // upper bound on the NN distance from the distance transform: DT(q) is exact between voxel centres,
-// query and neighbour are each within sqrt(3)/2 voxel of theirs (2.5 voxels of slack, squared)
+// query and neighbour are each within sqrt(3)/2 voxel of theirs (1.733 voxels; 1.75 used), squared
 template <int LAYOUT>
 __device__ __forceinline__ float nn_upper_bound(const DtDesc& dt, float qx, float qy, float qz)
 {
-	const float d = dt_distance<LAYOUT>(dt, qx, qy, qz) + (float)(2.5 / dt.scale);
+	const float d = dt_distance<LAYOUT>(dt, qx, qy, qz) + (float)(1.75 / dt.scale);
 	return d * d;
 }
 

@@ -5,10 +5,11 @@
 //   best-first BnB over the translation cube [-0.5,0.5]^3 (InnerBnB, :227-340), ICP refinement
 //   whenever the upper bound improves (:495-530), stop when best - lb <= SSEThresh.
 // What is MI355X-first here: the reference evaluates ONE cube per step; this driver keeps the same
-// bounds and the same queues but expands `trans_batch` translation nodes of up to 8 concurrent
-// inner searches per kernel launch (thousands of cube x point evaluations per launch instead of
-// one pass over N points).  Any expansion order of a best-first BnB yields valid bounds; with
-// trans_batch = 1 and wide_children = 0 the visit order is exactly the reference's.
+// bounds and the same queues but expands `trans_batch` translation nodes of every active inner search
+// per kernel launch, and `rot_batch` rotation nodes at once (their children's upper- and lower-bound
+// searches run in lock-step): thousands of cube x point evaluations per launch instead of one pass
+// over N points.  Any expansion order of a best-first BnB yields valid bounds; with trans_batch = 1
+// and wide_children = 0 the visit order is exactly the reference's.
 #include "engine.hpp"
 
 #include <algorithm>

@@ -609,12 +609,14 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 				}
 			}
 	};
-	bool fly[2] = {submit(0), !grp[1].empty() && submit(1)};
+	auto timed = [&](double& acc, auto&& fn) { const double t0 = now_ms(); auto r = fn(); acc += now_ms() - t0; return r; };
+	bool fly[2] = {timed(t_submit_, [&] { return submit(0); }), !grp[1].empty() && submit(1)};
 	while (fly[0] || fly[1])
 		for (int k = 0; k < 2; k++)
 			if (fly[k]) {
-				collect(k);
-				fly[k] = !cancel_.load() && submit(k);
+				timed(t_wait_, [&] { HIPCHK(hipEventSynchronize(stage_[k].ev)); return 0; });
+				timed(t_collect_, [&] { collect(k); return 0; });
+				fly[k] = !cancel_.load() && timed(t_submit_, [&] { return submit(k); });
 			}
 	HIPCHK(hipStreamSynchronize(stream_));
 }
@@ -694,7 +696,7 @@ void Engine::register_begin()
 {
 	cancel_.store(false);
 	early_exit_ = converged_ = false;
-	icp_ms_ = 0;
+	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
 	cnt_ = Counters{};
 	while (!queue_.empty()) queue_.pop();
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -866,8 +868,8 @@ void Engine::run()
 	}
 	register_ms_ = now_ms() - t0;
 	if (p_.verbose)
-		std::fprintf(stderr, "[goicp] register %.2f ms: inner BnB rounds %.2f ms (%lld launches), ICP + DT re-score %.2f ms (%lld passes)\n",
-		             register_ms_, bnb_ms_, cnt_.bounds_launches, icp_ms_, cnt_.icp_iters);
+		std::fprintf(stderr, "[goicp] register %.2f ms: inner BnB rounds %.2f ms (%lld launches: host build %.2f, GPU wait %.2f, host digest %.2f), ICP + DT re-score %.2f ms (%lld passes)\n",
+		             register_ms_, bnb_ms_, cnt_.bounds_launches, t_submit_, t_wait_, t_collect_, icp_ms_, cnt_.icp_iters);
 	register_end();
 }
 

@@ -164,7 +164,7 @@ private:
 	std::atomic<bool> cancel_{false};
 	std::mutex mtx_;
 	Result snap_{};
-	double dt_build_ms_ = 0, register_ms_ = 0, bnb_ms_ = 0, icp_ms_ = 0;
+	double dt_build_ms_ = 0, register_ms_ = 0, bnb_ms_ = 0, icp_ms_ = 0, t_submit_ = 0, t_wait_ = 0, t_collect_ = 0;
 	// icp_step state
 	float stepR_[9], stepT_[3];
 };

@@ -32,7 +32,7 @@ class CParams(C.Structure):
     _fields_ = [("dt_size", C.c_int32), ("dt_expand", C.c_double), ("mse_threshold", C.c_float),
                 ("dt_layout", C.c_int32), ("device", C.c_int32), ("trans_batch", C.c_int32),
                 ("wide_children", C.c_int32), ("icp_max_iter", C.c_int32), ("verbose", C.c_int32),
-                ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("trim_fraction", C.c_float)]
+                ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float)]
 
 
 class CCube(C.Structure):

@@ -446,9 +446,9 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 //   * children are entered nearest-box-first, and only while their box is within the best
 //     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes and min-reduced
 //     with DPP shuffles; after every improvement the pending ballots are re-filtered;
-//   * the search starts from the upper bound (DT(q) + 1.75 voxel)^2 read from the distance
-//     transform the engine already holds, so queries far from the surface prune as well as
-//     near ones;
+//   * the search starts from the upper bound (|q - centre(v)| + DT[v] + 0.9 voxel)^2 read from the
+//     distance transform the engine already holds, so queries far from the surface prune as
+//     well as near ones;
 //   * all control flow is wave-uniform: no divergence, no per-lane stack, no tail lanes.
 // Depth K = 2 covers 64*64*16 = 65 536 target points, K = 3 up to 4.2 M.
 // Exactness: box lower bounds use the same monotone float accumulation as the point distances and
@@ -555,12 +555,24 @@ __device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, const Box6& r
 	return r;
 }
 
-// upper bound on the NN distance from the distance transform: DT(q) is exact between voxel centres,
-// query and neighbour are each within sqrt(3)/2 voxel of theirs (1.733 voxels; 1.75 used), squared
+// Upper bound on the NN distance from the distance transform.  For ANY voxel v:
+//   d(q, NN) <= |q - centre(v)| + DT[v] + sqrt(3)/2 voxel
+// (DT[v] is the exact distance from v's centre to the centre of the nearest seed voxel, and a target
+// point lies within sqrt(3)/2 voxel of the centre of the voxel it seeded).  v = the grid voxel nearest
+// to q (clamped into the grid, so queries outside it are covered too); |q - centre(v)| is computed
+// explicitly, so neither the reference's index rounding nor its out-of-grid extension matters here.
+// 0.9 voxel + 1e-5 relative cover sqrt(3)/2 = 0.866 and the float rounding of this expression.
 template <int LAYOUT>
 __device__ __forceinline__ float nn_upper_bound(const DtDesc& dt, float qx, float qy, float qz)
 {
-	const float d = dt_distance<LAYOUT>(dt, qx, qy, qz) + (float)(1.75 / dt.scale);
+	const float inv = 1.0f / dt.scale_f;
+	const int V1 = dt.V - 1;
+	const int ix = min(max((int)rintf((qx - dt.xmin_f) * dt.scale_f), 0), V1);
+	const int iy = min(max((int)rintf((qy - dt.ymin_f) * dt.scale_f), 0), V1);
+	const int iz = min(max((int)rintf((qz - dt.zmin_f) * dt.scale_f), 0), V1);
+	const float cx = dt.xmin_f + (float)ix * inv, cy = dt.ymin_f + (float)iy * inv, cz = dt.zmin_f + (float)iz * inv;
+	const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+	const float d = (__fsqrt_rn(ex * ex + ey * ey + ez * ez) + dt_fetch<LAYOUT>(dt, ix, iy, iz) + 0.9f * inv) * 1.00001f;
 	return d * d;
 }
 

@@ -96,6 +96,10 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2,
                            hipStream_t stream);
 
+// ---- device-side build of the box hierarchy (kdbuild.hip): Morton sort + bottom-up boxes ----------
+hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], float ext, float* const boxes[kMaxLevels],
+                           float4* pts, hipStream_t stream);
+
 // ---- distance transform build (DT3D::Build, jly_3ddt.cpp:889-979; exact EDT) -------------------
 // work: V^3 int32 (linear).  out: V^3 floats in dt.layout (may alias work only for layout 0).
 hipError_t launch_dt_build(const float* model_xyz, int M, const DtDesc& dt, int32_t* work, float* out,

@@ -202,19 +202,39 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 		if (dt_.layout) HIPCHK(hipFree(d_work));
 		dt_build_ms_ = now_ms() - t0;
 	}
-	// ---- k-d tree over the target ----
+	// ---- k-d tree (64-ary box hierarchy) over the target ----
 	{
-		KdHost kh;
-		build_kdtree(target, (int)M_, kLeafSlots, &kh);
-		for (int l = 0; l < kh.K; l++) {
-			HIPCHK(hipMalloc(&d_kd_boxes_[l], sizeof(float) * kh.boxes[l].size()));
-			HIPCHK(hipMemcpy(d_kd_boxes_[l], kh.boxes[l].data(), sizeof(float) * kh.boxes[l].size(), hipMemcpyHostToDevice));
-			kd_.boxes[l] = d_kd_boxes_[l];
+		const bool gpu_build = p_.kd_gpu_build > 0 || (p_.kd_gpu_build < 0 && M_ > 262144);
+		if (!gpu_build) {
+			KdHost kh;
+			build_kdtree(target, (int)M_, kLeafSlots, &kh);
+			for (int l = 0; l < kh.K; l++) {
+				HIPCHK(hipMalloc(&d_kd_boxes_[l], sizeof(float) * kh.boxes[l].size()));
+				HIPCHK(hipMemcpy(d_kd_boxes_[l], kh.boxes[l].data(), sizeof(float) * kh.boxes[l].size(), hipMemcpyHostToDevice));
+			}
+			HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
+			HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
+			kd_.K = kh.K;
+		} else {
+			// device build: Morton sort + bottom-up boxes, no host tree
+			int K = 1;
+			while (K < kMaxLevels && (long long)kLeafSlots * (1LL << (6 * K)) < (long long)M_) K++;
+			if ((long long)kLeafSlots * (1LL << (6 * K)) < (long long)M_) throw std::invalid_argument("goicp: target cloud too large for the k-d tree");
+			float* d_model = nullptr;
+			HIPCHK(hipMalloc(&d_model, sizeof(float) * 3 * M_));
+			HIPCHK(hipMemcpyAsync(d_model, target, sizeof(float) * 3 * M_, hipMemcpyHostToDevice, stream_));
+			for (int l = 0; l < K; l++) HIPCHK(hipMalloc(&d_kd_boxes_[l], sizeof(float) * 384 * ((size_t)1 << (6 * l))));
+			HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kLeafSlots * ((size_t)1 << (6 * K))));
+			float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+			for (size_t i = 0; i < M_; i++)
+				for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], target[3 * i + k]); mx[k] = std::max(mx[k], target[3 * i + k]); }
+			const float ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]});
+			HIPCHK(launch_kd_build(d_model, (int)M_, K, mn, ext, d_kd_boxes_, d_kd_pts_, stream_));
+			HIPCHK(hipFree(d_model));
+			kd_.K = K;
 		}
-		for (int l = kh.K; l < kMaxLevels; l++) kd_.boxes[l] = nullptr;
-		HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
-		HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
-		kd_.pts = d_kd_pts_; kd_.K = kh.K; kd_.M = (int)M_;
+		for (int l = 0; l < kMaxLevels; l++) kd_.boxes[l] = d_kd_boxes_[l];
+		kd_.pts = d_kd_pts_; kd_.M = (int)M_;
 	}
 	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)std::max(icp_blocks((int)N_), icp_trim_blocks((int)N_)) * kIcpAcc));
 	if (inliers_ < (int)N_) {

@@ -27,6 +27,7 @@ struct Params {
 	int verbose = 0;
 	int morton_sort = 1;          // sort the source cloud along a Morton curve (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
+	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort): 1 yes, 0 host median splits, -1 auto (M > 262144)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 };
 

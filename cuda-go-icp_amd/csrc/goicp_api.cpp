@@ -81,7 +81,7 @@ void goicp_params_default(goicp_params* p)
 	goicp::Params d;
 	p->dt_size = d.dt_size; p->dt_expand = d.dt_expand; p->mse_threshold = d.mse_threshold; p->dt_layout = d.dt_layout;
 	p->device = d.device; p->trans_batch = d.trans_batch; p->wide_children = d.wide_children;
-	p->icp_max_iter = d.icp_max_iter; p->verbose = d.verbose; p->morton_sort = d.morton_sort; p->rot_batch = d.rot_batch; p->trim_fraction = d.trim_fraction;
+	p->icp_max_iter = d.icp_max_iter; p->verbose = d.verbose; p->morton_sort = d.morton_sort; p->rot_batch = d.rot_batch; p->trim_fraction = d.trim_fraction; p->kd_gpu_build = d.kd_gpu_build;
 }
 
 int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_target, const float* source_xyz,
@@ -99,6 +99,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 			p.morton_sort = params->morton_sort;
 			if (params->rot_batch > 0) p.rot_batch = params->rot_batch;
 			p.trim_fraction = params->trim_fraction;
+			p.kd_gpu_build = params->kd_gpu_build;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }

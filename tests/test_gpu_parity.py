@@ -527,3 +527,26 @@ def test_cli_end_to_end(pkg, tmp_path):
     assert pkg.load_cloud(tmp_path / "viz.ply").shape == (200, 3)
     bad = subprocess.run([exe, str(tmp_path / "missing.toml")], capture_output=True, text=True)
     assert bad.returncode == 1 and "error" in bad.stderr.lower()
+
+
+# ----------------------------------------------------------------------------------------------
+# device-side k-d tree build
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [35947, 120000, 700])
+def test_gpu_built_hierarchy_exact(pkg, oracle_mod, bunny_model, M):
+    """The Morton/rocPRIM-built box hierarchy gives the same exact neighbours as brute force (K = 1, 2, 3)."""
+    from cuda_go_icp_amd import synth
+    target = bunny_model if M == 35947 else synth.make_pair(seed=5, M=M, N=8)[0]
+    reg = pkg.Registration(target, target[:256], 1e-3, dt_size=96, kd_gpu_build=1)
+    rng = np.random.default_rng(8)
+    near = target[300:700]
+    q = np.concatenate([rng.uniform(-2.5, 2.5, (1500, 3)).astype(np.float32), target[:300],
+                        (near + rng.normal(0, 0.01, near.shape)).astype(np.float32)])
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    reg.close()
+
+
+def test_gpu_built_hierarchy_e2e(pkg, bunny_model, bunny_data10):
+    _e2e(pkg, "bunny10", bunny_model, bunny_data10, strict=True, trans_batch=1, wide_children=0, kd_gpu_build=1)

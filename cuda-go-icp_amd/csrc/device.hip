@@ -444,8 +444,9 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 //   * a wavefront owns one query; lane l tests child box l of the current group (6 coalesced
 //     256-B loads for the 64 boxes), the candidates are a 64-bit ballot;
 //   * children are entered nearest-box-first, and only while their box is within the best
-//     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes and min-reduced
-//     with DPP shuffles; after every improvement the pending ballots are re-filtered;
+//     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes, the improving
+//     lanes are a ballot walked with s_ff1 + v_readlane; after every improvement the pending
+//     ballots are re-filtered;
 //   * the search starts from the upper bound (|q - centre(v)| + DT[v] + 0.9 voxel)^2 read from the
 //     distance transform the engine already holds, so queries far from the surface prune as
 //     well as near ones;

@@ -392,9 +392,9 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 static void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts)
 {
 	int g = (B + kGroup - 1) / kGroup;
-	// aim for >= 8 blocks of 256 threads per CU (256 CUs) so that the gathers have 32 waves/CU, and
+	// aim for >= 4 blocks of 256 threads per CU (256 CUs) even for small batches, and
 	// for a multiple of 8 point chunks (one set per XCD) whenever the cloud is large enough
-	const int target_blocks = 2048;
+	const int target_blocks = 1024;   // measured on the BnB's small batches: 512..2048 within 5 %, larger is slower
 	const int max_chunks = (N + kBoundsThreads - 1) / kBoundsThreads;
 	int c = (target_blocks + g - 1) / g;
 	if (max_chunks >= 8) c = (c + 7) / 8 * 8;

@@ -102,8 +102,12 @@ __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float q
 	if (x < 0) { a = (float)x; x = 0; } else if (x >= V) { a = (float)(x - V + 1); x = V - 1; }
 	if (y < 0) { b = (float)y; y = 0; } else if (y >= V) { b = (float)(y - V + 1); y = V - 1; }
 	if (z < 0) { c = (float)z; z = 0; } else if (z >= V) { c = (float)(z - V + 1); z = V - 1; }
-	float r = __fsqrt_rn(a * a + b * b + c * c);
-	return (float)((double)r / dt.scale + (double)dt_fetch<LAYOUT>(dt, x, y, z));
+	// sqrt(a^2+b^2+c^2)/scale: a, b, c are small integers, so the term is a function of the integer
+	// s = a^2+b^2+c^2 only.  DtDesc.overshoot[s] holds (double)sqrtf(s)/scale computed on the host with
+	// the same operations (bit-identical), which replaces a float sqrt and an fp64 division on this path.
+	const int si = (int)(a * a + b * b + c * c);
+	const double ext = si < dt.n_overshoot ? dt.overshoot[si] : (double)__fsqrt_rn(a * a + b * b + c * c) / dt.scale;
+	return (float)(ext + (double)dt_fetch<LAYOUT>(dt, x, y, z));
 }
 
 // Per-axis part of a voxel's element offset.  Both layouts are separable: offset = fx(x)+fy(y)+fz(z);

@@ -21,6 +21,8 @@ struct DtDesc {
 	// float images of the geometry + the error model of the float index fast path (device.hip voxel_fast)
 	float scale_f, xmin_f, ymin_f, zmin_f;
 	float c1, c2;   // |F_float - F_exact| <= c1 + c2*|F|
+	const double* overshoot;   // [n_overshoot]: (double)sqrtf(s)/scale for the out-of-grid extension (jly_3ddt.cpp:1025)
+	int n_overshoot;
 };
 
 // One translation sub-cube to bound (the inner body of GoICP::InnerBnB, jly_goicp.cpp:262-315).

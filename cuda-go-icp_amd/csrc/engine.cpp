@@ -196,6 +196,15 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 			d_dt_ = reinterpret_cast<float*>(d_work);
 		}
 		dt_.grid = d_dt_;
+		{   // table of the out-of-grid extension term, same float sqrt + double divide as the kernel's fallback
+			const int n = 16384;
+			std::vector<double> tab(n);
+			for (int i = 0; i < n; i++) tab[i] = (double)std::sqrt((float)i) / dt_.scale;
+			HIPCHK(hipMalloc(&d_overshoot_, sizeof(double) * n));
+			HIPCHK(hipMemcpyAsync(d_overshoot_, tab.data(), sizeof(double) * n, hipMemcpyHostToDevice, stream_));
+			HIPCHK(hipStreamSynchronize(stream_));
+			dt_.overshoot = d_overshoot_; dt_.n_overshoot = n;
+		}
 		HIPCHK(launch_dt_build(d_model, (int)M_, dt_, d_work, d_dt_, stream_));
 		HIPCHK(hipStreamSynchronize(stream_));
 		HIPCHK(hipFree(d_model));
@@ -255,7 +264,7 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 Engine::~Engine()
 {
 	hipStreamSynchronize(stream_);
-	hipFree(d_src_); hipFree(d_dt_);
+	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_);
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);

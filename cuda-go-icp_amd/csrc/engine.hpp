@@ -135,6 +135,7 @@ private:
 	float src_centroid_[3] = {0, 0, 0}, model_centroid_[3] = {0, 0, 0};
 	DtDesc dt_{};
 	float* d_dt_ = nullptr;
+	double* d_overshoot_ = nullptr;
 	// k-d tree
 	KdDesc kd_{};
 	float* d_kd_boxes_[kMaxLevels] = {nullptr, nullptr, nullptr}; float4* d_kd_pts_ = nullptr;

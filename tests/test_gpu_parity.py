@@ -550,3 +550,31 @@ def test_gpu_built_hierarchy_exact(pkg, oracle_mod, bunny_model, M):
 
 def test_gpu_built_hierarchy_e2e(pkg, bunny_model, bunny_data10):
     _e2e(pkg, "bunny10", bunny_model, bunny_data10, strict=True, trans_batch=1, wide_children=0, kd_gpu_build=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# result API under concurrency (the reference's viewer polls the worker: src/goicp_kernel.cu:161-177)
+# ----------------------------------------------------------------------------------------------
+def test_poll_and_cancel_while_running(pkg, bunny_model, bunny_data):
+    """goicp_poll from another thread returns consistent snapshots (best error never increases, optR stays
+    a rotation) while goicp_register runs; goicp_cancel (the reference's `goicp_finished` flag) stops it."""
+    import threading
+    import time
+    eng = pkg.FastGoICP(bunny_model, bunny_data, 1e-9, trans_batch=1, wide_children=0)   # threshold too tight to finish soon
+    th = threading.Thread(target=eng.run)
+    th.start()
+    seen = []
+    t0 = time.time()
+    while time.time() - t0 < 1.5:
+        r = eng.registration.poll()
+        R = np.array(r.optR, np.float64).reshape(3, 3)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-4
+        seen.append(float(r.best_sse))
+        assert not r.finished
+        time.sleep(0.01)
+    assert all(b <= a for a, b in zip(seen, seen[1:]))
+    assert th.is_alive()
+    eng.cancel()
+    th.join(timeout=30)
+    assert not th.is_alive() and eng.finished
+    assert eng.get_best_error() <= seen[-1]

@@ -74,6 +74,16 @@ float Engine::rot_coeff(int level) const
 Engine::Engine(const Params& p, const float* target, size_t M, const float* source, size_t N)
     : p_(p), M_(M), N_(N)
 {
+	try {
+		init(target, M, source, N);
+	} catch (...) {
+		release();      // a half-built engine must not leak device memory
+		throw;
+	}
+}
+
+void Engine::init(const float* target, size_t M, const float* source, size_t N)
+{
 	if (!target || !source || M == 0 || N == 0) throw std::invalid_argument("goicp: empty target or source cloud");
 	if (M > (size_t)INT32_MAX / 8 || N > (size_t)INT32_MAX / 8) throw std::invalid_argument("goicp: cloud too large");
 	if (p_.dt_size < 8 || p_.dt_size > 640) throw std::invalid_argument("goicp: dt_size must be in [8,640]");
@@ -261,9 +271,11 @@ Engine::Engine(const Params& p, const float* target, size_t M, const float* sour
 	publish(false);
 }
 
-Engine::~Engine()
+Engine::~Engine() { release(); }
+
+void Engine::release()
 {
-	hipStreamSynchronize(stream_);
+	if (stream_) hipStreamSynchronize(stream_);
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_);
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
@@ -275,9 +287,18 @@ Engine::~Engine()
 		hipFree(st.d_cubes); hipFree(st.d_ub); hipFree(st.d_lb);
 		hipHostFree(st.h_cubes); hipHostFree(st.h_ub); hipHostFree(st.h_lb);
 		if (st.ev) hipEventDestroy(st.ev);
+		st = Stage{};
 	}
-	hipEventDestroy(ev0_); hipEventDestroy(ev1_);
-	hipStreamDestroy(stream_);
+	if (ev0_) hipEventDestroy(ev0_);
+	if (ev1_) hipEventDestroy(ev1_);
+	if (stream_) hipStreamDestroy(stream_);
+	d_src_ = nullptr; d_dt_ = nullptr; d_overshoot_ = nullptr; d_kd_pts_ = nullptr;
+	for (int l = 0; l < kMaxLevels; l++) d_kd_boxes_[l] = nullptr;
+	d_cubes_ = nullptr; d_rots_ = nullptr; d_ub_ = d_lb_ = d_scratch_ = nullptr;
+	h_cubes_ = nullptr; h_rots_ = nullptr; h_ub_ = h_lb_ = nullptr;
+	d_icp_partials_ = nullptr; d_icp_state_ = nullptr; h_icp_state_ = nullptr;
+	d_nn_d2_ = nullptr; d_nn_slot_ = nullptr; d_include_ = nullptr;
+	ev0_ = ev1_ = nullptr; stream_ = nullptr;
 }
 
 void Engine::ensure_batch(size_t B, size_t K)

@@ -110,6 +110,8 @@ public:
 
 private:
 	struct InnerSearch;
+	void init(const float* target_xyz, size_t M, const float* source_xyz, size_t N);
+	void release();
 	void ensure_batch(size_t B, size_t K);
 	void ensure_stage(int k, size_t B);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "device.hpp"
 
@@ -628,6 +629,202 @@ __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __r
 	}
 }
 
+// ---- four queries per wavefront (K = 2 hierarchies, i.e. up to 65 536 target points) ------------------
+// The wave-per-query pass above is instruction-issue bound (~1250 wave-instructions per query, most
+// of them the scalar ballot-walking loops).  Here a wavefront is four 16-lane rows; each row owns one
+// query, each lane four of the 64 children of the current group, and a leaf's 16 slots map onto the
+// row's 16 lanes.  Minima inside a row are DPP butterflies (quad_perm, row_half_mirror, row_mirror):
+// no scalar loops, no LDS, four queries per issued instruction.  Rows are at different stages of
+// their walks, so one loop iteration runs (at most) the two step kinds "enter the nearest pending
+// group" and "scan the nearest pending leaf" under the rows' exec masks.  Same exactness argument.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+	return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned row_min_u32(unsigned v)      // min over the lane's 16-lane row, in every lane
+{
+	v = min(v, dpp_u32<0xB1>(v));     // quad_perm [1,0,3,2]
+	v = min(v, dpp_u32<0x4E>(v));     // quad_perm [2,3,0,1]
+	v = min(v, dpp_u32<0x141>(v));    // row_half_mirror
+	v = min(v, dpp_u32<0x140>(v));    // row_mirror
+	return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum_f32(float v)            // sum over the lane's 16-lane row, in every lane
+{
+	v += dpp_f32<0xB1>(v);
+	v += dpp_f32<0x4E>(v);
+	v += dpp_f32<0x141>(v);
+	v += dpp_f32<0x140>(v);
+	return v;
+}
+
+struct Box6x4 { float4 lox, loy, loz, hix, hiy, hiz; };   // the four children 4l..4l+3 of a lane
+__device__ __forceinline__ Box6x4 load_child_boxes4(const float* __restrict__ g, int l)
+{
+	const float4* r = reinterpret_cast<const float4*>(g);
+	return Box6x4{r[l], r[16 + l], r[32 + l], r[48 + l], r[64 + l], r[80 + l]};
+}
+__device__ __forceinline__ float box_lb1(float lox, float loy, float loz, float hix, float hiy, float hiz, float qx, float qy, float qz)
+{
+	const float ex = fmaxf(fmaxf(lox - qx, qx - hix), 0.f);
+	const float ey = fmaxf(fmaxf(loy - qy, qy - hiy), 0.f);
+	const float ez = fmaxf(fmaxf(loz - qz, qz - hiz), 0.f);
+	float d = ex * ex;
+	d += ey * ey;
+	d += ez * ez;
+	return d;
+}
+__device__ __forceinline__ void boxes_lb4(const Box6x4& b, float qx, float qy, float qz, float lb[4])
+{
+	lb[0] = box_lb1(b.lox.x, b.loy.x, b.loz.x, b.hix.x, b.hiy.x, b.hiz.x, qx, qy, qz);
+	lb[1] = box_lb1(b.lox.y, b.loy.y, b.loz.y, b.hix.y, b.hiy.y, b.hiz.y, qx, qy, qz);
+	lb[2] = box_lb1(b.lox.z, b.loy.z, b.loz.z, b.hix.z, b.hiy.z, b.hiz.z, qx, qy, qz);
+	lb[3] = box_lb1(b.lox.w, b.loy.w, b.loz.w, b.hix.w, b.hiy.w, b.hiz.w, qx, qy, qz);
+}
+// nearest pending child of the row: key = distance bits with the two low mantissa bits replaced by the
+// child's sub-index (ordering only), row minimum, owner lane from the ballot.  Returns the child 0..63 or -1.
+__device__ __forceinline__ int row_pick(const float lb[4], unsigned pend, int l, int row, unsigned& pend_out)
+{
+	unsigned key = 0xffffffffu;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const unsigned k = (__float_as_uint(lb[j]) & ~3u) | (unsigned)j;
+		key = ((pend >> j) & 1u) ? min(key, k) : key;
+	}
+	const unsigned m = row_min_u32(key);
+	const unsigned owners = (unsigned)(__ballot(key == m && m != 0xffffffffu) >> (16 * row)) & 0xffffu;
+	pend_out = pend;
+	if (m == 0xffffffffu) return -1;
+	const int wl = __ffs((int)owners) - 1;
+	const int j = (int)(m & 3u);
+	if (l == wl) pend_out = pend & ~(1u << j);
+	return 4 * wl + j;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kIcpThreads) void icp_pass_rows_kernel(const float4* __restrict__ src, int N,
+                                                                    const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
+                                                                    float* __restrict__ partials)
+{
+	__shared__ float red[kIcpThreads / 64][kIcpAcc];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
+	const int w = blockIdx.x * (kIcpThreads / 64) + wave;
+	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
+	const int i = w * 4 + row;
+	const bool valid = i < N;
+	const float4 p = src[valid ? i : N - 1];
+	if (st->converged) return;
+	float acc[kIcpAcc];
+#pragma unroll
+	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
+	{
+		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+		// The child of the root with the smallest box distance always survives any bound (the true
+		// neighbour's child has lb <= d_nn), so its boxes are fetched together with the DT seed
+		// instead of after it: one dependent memory round trip less.
+		float lb0[4], lb1[4];
+		boxes_lb4(rootb, qx, qy, qz, lb0);
+		unsigned pend0 = 0xFu, pend1 = 0;
+		int group = row_pick(lb0, pend0, l, row, pend0);
+		const Box6x4 fb = load_child_boxes4(kd.boxes[1] + (size_t)group * 384, l);
+		float best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
+		int bidx = INT_MAX;
+		bool mine = false;                        // this lane holds the row's current nearest point
+		float mx = 0.f, my = 0.f, mz = 0.f;
+		boxes_lb4(fb, qx, qy, qz, lb1);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			if (!(lb0[j] <= best)) pend0 &= ~(1u << j);
+			pend1 |= (lb1[j] <= best ? 1u : 0u) << j;
+		}
+		bool done = !valid;
+		while (__any(!done)) {
+			const bool has1 = ((unsigned)(__ballot(pend1 != 0u) >> (16 * row)) & 0xffffu) != 0u;
+			if (!done && has1) {
+				// ---- scan the two nearest pending leaves of the current group: one slot per lane each ----
+				const int ca = row_pick(lb1, pend1, l, row, pend1);
+				const int cb = row_pick(lb1, pend1, l, row, pend1);
+				const float4 pa = kd.pts[(group * 64 + ca) * kLeafSlots + l];
+				float4 pt = kd.pts[(group * 64 + (cb < 0 ? ca : cb)) * kLeafSlots + l];
+				float d, e;
+				{
+					const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
+					d = d0 * d0;                                     // L2_Simple_Adaptor accumulation order
+					d += d1 * d1;
+					d += d2 * d2;
+					const float e0 = qx - pt.x, e1 = qy - pt.y, e2 = qz - pt.z;
+					e = e0 * e0;
+					e += e1 * e1;
+					e += e2 * e2;
+				}
+				if (d < e || (d == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = d; }
+				const unsigned db = __float_as_uint(e);
+				const unsigned dmin = row_min_u32(db);
+				const unsigned id = (unsigned)__float_as_int(pt.w);
+				const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);      // ties -> lowest original index
+				const float dm = __uint_as_float(dmin);
+				if (dm < best || (dm == best && (int)idmin < bidx)) {
+					best = dm;
+					bidx = (int)idmin;
+					mine = db == dmin && id == idmin;
+					mx = pt.x; my = pt.y; mz = pt.z;
+				}
+#pragma unroll
+				for (int j = 0; j < 4; j++) {                        // re-filter with the improved bound
+					if (!(lb1[j] <= best)) pend1 &= ~(1u << j);
+					if (!(lb0[j] <= best)) pend0 &= ~(1u << j);
+				}
+			} else if (!done) {
+				// ---- enter the nearest pending group of the root (or finish) ----
+				const int c = row_pick(lb0, pend0, l, row, pend0);
+				if (c < 0) {
+					done = true;
+				} else {
+					group = c;
+					const Box6x4 cb = load_child_boxes4(kd.boxes[1] + (size_t)group * 384, l);
+					boxes_lb4(cb, qx, qy, qz, lb1);
+					pend1 = 0;
+#pragma unroll
+					for (int j = 0; j < 4; j++) pend1 |= (lb1[j] <= best ? 1u : 0u) << j;
+				}
+			}
+		}
+		if (valid && mine) {                          // exactly one lane of the row
+			const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];
+			const float bx = mx - st->cm[0], by = my - st->cm[1], bz = mz - st->cm[2];
+			acc[0] += ax; acc[1] += ay; acc[2] += az;
+			acc[3] += bx; acc[4] += by; acc[5] += bz;
+			acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
+			acc[9] += ay * bx; acc[10] += ay * by; acc[11] += ay * bz;
+			acc[12] += az * bx; acc[13] += az * by; acc[14] += az * bz;
+			acc[15] += best;
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < kIcpAcc; k++) {
+		float v = row_sum_f32(acc[k]);                // fixed butterfly order: deterministic
+		v += __shfl_xor(v, 16, 64);
+		v += __shfl_xor(v, 32, 64);
+		if (lane == 0) red[wave][k] = v;
+	}
+	__syncthreads();
+	if (threadIdx.x < kIcpAcc) {
+		float sum = red[0][threadIdx.x];
+#pragma unroll
+		for (int x = 1; x < kIcpThreads / 64; x++) sum += red[x][threadIdx.x];
+		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = sum;
+	}
+}
+
 // ---- trimmed ICP (trim_fraction > 0; jly_icp3d.hpp:236-252): NN for every point, exact selection of
 // the `num` smallest squared distances (radix select, ties in point order), sums over the selected ----
 template <int K, int LAYOUT>
@@ -814,29 +1011,51 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
                                                                      IcpState* __restrict__ state)
 {
-	if (state->converged) return;
-	__shared__ double stream[64][kIcpAcc];
+	__shared__ double wsum[kIcpAcc][kIcpAcc];      // [wavefront][component]
 	__shared__ double sums[kIcpAcc];
-	// 64 row streams x 16 components, 4 independent accumulators per thread (loads stay in flight),
-	// then fixed-order sums: deterministic
-	const int k = threadIdx.x & (kIcpAcc - 1), r = threadIdx.x >> 4;
-	double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-	for (int b = r; b < nblocks; b += 256) {
-		a0 += (double)partials[(size_t)b * kIcpAcc + k];
-		if (b + 64 < nblocks) a1 += (double)partials[(size_t)(b + 64) * kIcpAcc + k];
-		if (b + 128 < nblocks) a2 += (double)partials[(size_t)(b + 128) * kIcpAcc + k];
-		if (b + 192 < nblocks) a3 += (double)partials[(size_t)(b + 192) * kIcpAcc + k];
+	// This kernel is a chain of dependent memory round trips (~1-2 us each: the partials were written
+	// by other XCDs), so everything it needs -- the state, and up to 2048 partial rows at a time as
+	// eight float4 loads per thread -- is requested before anything is waited for.  256 row streams x
+	// four float4 columns; fixed-order sums (registers, xor-butterfly inside a wavefront, then the 16
+	// wavefront totals in order): deterministic.
+	const int q = threadIdx.x & 3, r = threadIdx.x >> 2;
+	const float4* __restrict__ P = reinterpret_cast<const float4*>(partials);
+	IcpState st;
+	if (threadIdx.x == 0) st = *state;            // one burst of loads; the serial part below runs on registers
+	double a[4] = {0.0, 0.0, 0.0, 0.0};
+	for (int b0 = 0; b0 < nblocks; b0 += 256 * 8) {
+		float4 v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int b = b0 + r + 256 * j;
+			v[j] = b < nblocks ? P[(size_t)b * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			a[0] += (double)v[j].x;
+			a[1] += (double)v[j].y;
+			a[2] += (double)v[j].z;
+			a[3] += (double)v[j].w;
+		}
 	}
-	stream[r][k] = (a0 + a1) + (a2 + a3);
+	if (state->converged) return;                 // uniform; the pass kernel left the partials untouched
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		double x = a[c];
+		x += __shfl_xor(x, 4, 64);
+		x += __shfl_xor(x, 8, 64);
+		x += __shfl_xor(x, 16, 64);
+		x += __shfl_xor(x, 32, 64);
+		if ((threadIdx.x & 63) < 4) wsum[threadIdx.x >> 6][4 * q + c] = x;
+	}
 	__syncthreads();
 	if (threadIdx.x < kIcpAcc) {
-		double s = 0.0;
-		for (int i = 0; i < 64; i++) s += stream[i][threadIdx.x];
-		sums[threadIdx.x] = s;
+		double t = 0.0;
+		for (int i = 0; i < kIcpAcc; i++) t += wsum[i][threadIdx.x];
+		sums[threadIdx.x] = t;
 	}
 	__syncthreads();
 	if (threadIdx.x != 0) return;
-	IcpState st = *state;            // one burst of loads; the serial part below runs on registers
 	const float err_new = (float)sums[15];
 	st.err_new = err_new;
 	st.passes += 1;
@@ -928,9 +1147,28 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 	return hipGetLastError();
 }
 
+// GOICP_ICP_ROWS=0 forces the wavefront-per-query pass for K = 2 as well (A/B runs, tests)
+static bool icp_rows_enabled()
+{
+	const char* e = getenv("GOICP_ICP_ROWS");
+	return !(e && e[0] == '0');
+}
+int icp_rows_blocks(int N)
+{
+	const int per_block = (kIcpThreads / 64) * 4;
+	return (N + per_block - 1) / per_block;
+}
+
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
                                 hipStream_t stream)
 {
+	if (kd.K == 2 && icp_rows_enabled()) {
+		const dim3 grid(icp_rows_blocks(N)), block(kIcpThreads);
+		if (dt.layout) hipLaunchKernelGGL(icp_pass_rows_kernel<1>, grid, block, 0, stream, src, N, st, kd, dt, partials);
+		else hipLaunchKernelGGL(icp_pass_rows_kernel<0>, grid, block, 0, stream, src, N, st, kd, dt, partials);
+		hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, icp_rows_blocks(N), st);
+		return hipGetLastError();
+	}
 	if (kd.K == 1) launch_pass_k<1>(src, N, st, kd, dt, partials, stream);
 	else if (kd.K == 2) launch_pass_k<2>(src, N, st, kd, dt, partials, stream);
 	else launch_pass_k<3>(src, N, st, kd, dt, partials, stream);

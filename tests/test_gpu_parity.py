@@ -235,9 +235,12 @@ def test_nn_three_level_hierarchy(pkg, oracle_mod):
     reg.close()
 
 
-def test_icp_run_golden(pkg, reg10):
+@pytest.mark.parametrize("rows", ["1", "0"])
+def test_icp_run_golden(pkg, reg10, monkeypatch, rows):
     """IterativeClosestPoint3D::run / ICP3D::Run with forced iteration counts: 1e-4 abs on R,t for
-    <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3."""
+    <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3.  Both correspondence-pass kernels:
+    four queries per wavefront (default for two-level hierarchies) and one query per wavefront."""
+    monkeypatch.setenv("GOICP_ICP_ROWS", rows)
     g = golden("icp_iter")
     for c in g["cases"]:
         icp = pkg.IterativeClosestPoint3D(reg10, c["max_iter"], c["err_diff"], c["R0"], c["t0"])
@@ -248,6 +251,17 @@ def test_icp_run_golden(pkg, reg10):
         assert abs(err - c["err"]) <= 1e-3 * c["err"]
         if c["max_iter"] <= 10:
             assert icp.iters == c["max_iter"]
+
+
+@pytest.mark.parametrize("rows", ["1", "0"])
+def test_icp_first_pass_error_is_bruteforce_nn_sum(pkg, oracle_mod, bunny_model, bunny_data10, monkeypatch, rows):
+    """The correspondence pass is exact: its error equals the brute-force nearest-neighbour sum."""
+    monkeypatch.setenv("GOICP_ICP_ROWS", rows)
+    reg = pkg.Registration(bunny_model, bunny_data10, 1e-3)
+    _, d2 = oracle_mod.nn_brute(bunny_model, bunny_data10)
+    err = reg.icp_step().best_sse
+    assert abs(err - float(np.sum(d2.astype(np.float64)))) <= 5e-6 * float(np.sum(d2))
+    reg.close()
 
 
 def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):

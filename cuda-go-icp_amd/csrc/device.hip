@@ -440,126 +440,34 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 }
 
 // ------------------------------------------------------------------------------------------------
-// (b) ICP: exact 1-NN in the flattened k-d tree -- one WAVEFRONT per query, 64-ary.
+// (b) ICP: exact 1-NN in the flattened k-d tree -- 64-ary, four queries per WAVEFRONT.
 // Measured on MI355X, a per-lane walk of a binary tree is hopeless at this size: 30 k queries are
 // only 475 wavefronts, every step is a dependent, divergent access, and a wave is as slow as its
 // unluckiest lane (1.3 ms per pass, 3.9 ms for queries far from the surface).  So the tree the
-// host builds by median splits is flattened into a 64-ary hierarchy of tight bounding boxes --
-// branching factor = wave width:
-//   * a wavefront owns one query; lane l tests child box l of the current group (6 coalesced
-//     256-B loads for the 64 boxes), the candidates are a 64-bit ballot;
-//   * children are entered nearest-box-first, and only while their box is within the best
-//     distance; a leaf (<= 16 points, one 256-B block) is scanned by 16 lanes, the improving
-//     lanes are a ballot walked with s_ff1 + v_readlane; after every improvement the pending
-//     ballots are re-filtered;
+// host builds by median splits is flattened into a 64-ary hierarchy of tight bounding boxes, walked
+// cooperatively:
+//   * a wavefront is four 16-lane rows; a row owns one query, each of its lanes four of the 64
+//     child boxes of the current group (six float4 loads per lane), and a leaf's 16 slots map onto
+//     the row's 16 lanes;
+//   * minima inside a row are DPP butterflies (quad_perm, row_half_mirror, row_mirror) -- no scalar
+//     loops, no LDS, no per-lane stack; "any lane of my row" is a slice of a ballot;
+//   * children are entered nearest-box-first and only while their box is within the best distance;
+//     the two nearest pending leaves are scanned per step (two loads in flight, one wait), and
+//     after every improvement the pending masks of all levels are re-filtered;
 //   * the search starts from the upper bound (|q - centre(v)| + DT[v] + 0.9 voxel)^2 read from the
 //     distance transform the engine already holds, so queries far from the surface prune as
-//     well as near ones;
-//   * all control flow is wave-uniform: no divergence, no per-lane stack, no tail lanes.
+//     well as near ones; the nearest child of the root is fetched together with that seed;
+//   * rows are at different stages of their walks, so one loop iteration runs (at most) the two
+//     step kinds "enter a group" and "scan leaves" under the rows' exec masks.
+// History (bunny, 30 379 queries, converged pose, per pass): per-lane binary walk 1300 us; one
+// wavefront per query with ballot/readlane loops 42 us (instruction-issue bound, ~1250
+// wave-instructions per query); this kernel 26 us (~440 per query; what is left is the chain of
+// dependent memory round trips of the slowest wavefront).
 // Depth K = 2 covers 64*64*16 = 65 536 target points, K = 3 up to 4.2 M.
 // Exactness: box lower bounds use the same monotone float accumulation as the point distances and
 // the boxes are exact, ties go to the lowest original index -> identical to a brute-force scan.
 // ------------------------------------------------------------------------------------------------
-constexpr int kIcpThreads = 256;     // 4 wavefronts per workgroup
-constexpr int kIcpQueriesPerWave = 2;
-
-struct NnResult { float best; int idx; int slot; float mx, my, mz; };
-struct Box6 { float lox, loy, loz, hix, hiy, hiz; };   // one child box per lane
-
-__device__ __forceinline__ Box6 load_child_box(const float* __restrict__ g, int lane)
-{
-	// group record: lo_x[64] lo_y[64] lo_z[64] hi_x[64] hi_y[64] hi_z[64]
-	return Box6{g[lane], g[64 + lane], g[128 + lane], g[192 + lane], g[256 + lane], g[320 + lane]};
-}
-
-__device__ __forceinline__ float box_lb(const Box6& b, float qx, float qy, float qz)
-{
-	const float ex = fmaxf(fmaxf(b.lox - qx, qx - b.hix), 0.f);
-	const float ey = fmaxf(fmaxf(b.loy - qy, qy - b.hiy), 0.f);
-	const float ez = fmaxf(fmaxf(b.loz - qz, qz - b.hiz), 0.f);
-	float d = ex * ex;         // same accumulation order as the point distance
-	d += ey * ey;
-	d += ez * ez;
-	return d;                  // +inf for an empty child (lo = +inf, hi = -inf)
-}
-
-// The candidate sets are small (a handful of lanes), so minima are taken with a scalar loop over the
-// set bits of a ballot (s_ff1 + v_readlane) instead of 64-lane shuffle ladders.
-__device__ __forceinline__ int nearest_pending(float lb, unsigned long long pending)
-{
-	int best_c = -1;
-	float best_v = INFINITY;
-	while (pending) {
-		const int c = __ffsll((long long)pending) - 1;
-		pending &= pending - 1;
-		const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), c));
-		if (best_c < 0 || v < best_v) { best_v = v; best_c = c; }
-	}
-	return best_c;
-}
-
-__device__ __forceinline__ void scan_leaf(const KdDesc& kd, int leaf, int lane, float qx, float qy, float qz, NnResult& r)
-{
-	float d = INFINITY; int id = INT_MAX;
-	float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (lane < kLeafSlots) {
-		p = kd.pts[leaf * kLeafSlots + lane];
-		// squared L2 in the adaptor's accumulation order (nanoflann_goicp.hpp L2_Simple_Adaptor)
-		const float d0 = qx - p.x, d1 = qy - p.y, d2 = qz - p.z;
-		d = d0 * d0;
-		d += d1 * d1;
-		d += d2 * d2;
-		id = __float_as_int(p.w);
-	}
-	// lanes whose point beats the current best (ties -> lowest original index); usually none or one
-	unsigned long long better = __ballot(d < r.best || (d == r.best && id < r.idx));
-	while (better) {
-		const int c = __ffsll((long long)better) - 1;
-		better &= better - 1;
-		const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), c));
-		const int iv = __builtin_amdgcn_readlane(id, c);
-		if (dv < r.best || (dv == r.best && iv < r.idx)) {
-			r.best = dv; r.idx = iv; r.slot = leaf * kLeafSlots + c;
-			r.mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), c));   // the matched point rides along
-			r.my = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), c));
-			r.mz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), c));
-		}
-	}
-}
-
-template <int K, int LVL>
-__device__ __forceinline__ void visit_group(const KdDesc& kd, int group, const Box6& mybox, int lane, float qx, float qy, float qz, NnResult& r)
-{
-	const float lb = box_lb(mybox, qx, qy, qz);
-	unsigned long long pending = __ballot(lb <= r.best);
-	bool first = true;
-	while (pending) {
-		// the nearest pending child first (it usually holds the neighbour and shrinks the bound), the rest in
-		// index order: measured 93 / 66 us per pass (identity / converged pose) against 122 / 73 us for
-		// always-nearest and 109 / 82 us for pure index order -- the pass is instruction-issue bound
-		const int c = first ? nearest_pending(lb, pending) : (__ffsll((long long)pending) - 1);
-		first = false;
-		pending &= ~(1ull << c);
-		const int child = group * 64 + c;
-		if (LVL == K - 1) scan_leaf(kd, child, lane, qx, qy, qz, r);
-		else {
-			constexpr int NL = LVL + 1 < K ? LVL + 1 : LVL;
-			const Box6 cb = load_child_box(kd.boxes[NL] + (size_t)child * 384, lane);
-			visit_group<K, NL>(kd, child, cb, lane, qx, qy, qz, r);
-		}
-		pending &= __ballot(lb <= r.best);                              // re-filter with the improved bound
-	}
-}
-
-// exact 1-NN of one query by the whole wavefront (all lanes hold the same q and get the same result);
-// rootbox = this lane's child box of the root group, loaded once per wavefront
-template <int K>
-__device__ __forceinline__ NnResult wave_nearest(const KdDesc& kd, const Box6& rootbox, int lane, float qx, float qy, float qz, float bound)
-{
-	NnResult r{bound, INT_MAX, 0, 0.f, 0.f, 0.f};
-	visit_group<K, 0>(kd, 0, rootbox, lane, qx, qy, qz, r);
-	return r;
-}
+constexpr int kIcpThreads = 256;     // 4 wavefronts = 16 queries per workgroup
 
 // Upper bound on the NN distance from the distance transform.  For ANY voxel v:
 //   d(q, NN) <= |q - centre(v)| + DT[v] + sqrt(3)/2 voxel
@@ -582,61 +490,6 @@ __device__ __forceinline__ float nn_upper_bound(const DtDesc& dt, float qx, floa
 	return d * d;
 }
 
-template <int K, int LAYOUT>
-__global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
-                                                               const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
-                                                               float* __restrict__ partials)
-{
-	__shared__ float red[kIcpThreads / 64][kIcpAcc];
-	if (st->converged) return;                                          // loop already finished: queued launches drain
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int w = blockIdx.x * (kIcpThreads / 64) + wave;               // global wavefront index
-	const Box6 rootbox = load_child_box(kd.boxes[0], lane);
-	float acc[kIcpAcc];
-#pragma unroll
-	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
-	for (int j = 0; j < kIcpQueriesPerWave; j++) {
-		const int i = w * kIcpQueriesPerWave + j;
-		if (i >= N) break;                                               // wave-uniform
-		const float4 p = src[i];
-		// jly_icp3d.hpp:222-224, left-to-right float sums
-		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-		const NnResult r = wave_nearest<K>(kd, rootbox, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
-		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
-		const float bx = r.mx - st->cm[0], by = r.my - st->cm[1], bz = r.mz - st->cm[2];
-		acc[0] += ax; acc[1] += ay; acc[2] += az;
-		acc[3] += bx; acc[4] += by; acc[5] += bz;
-		acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
-		acc[9] += ay * bx; acc[10] += ay * by; acc[11] += ay * bz;
-		acc[12] += az * bx; acc[13] += az * by; acc[14] += az * bz;
-		acc[15] += r.best;
-	}
-	// every lane of a wave holds the same sums: lane k publishes component k
-	if (lane < kIcpAcc) {
-		float v = 0.f;
-#pragma unroll
-		for (int k = 0; k < kIcpAcc; k++) v = lane == k ? acc[k] : v;
-		red[wave][lane] = v;
-	}
-	__syncthreads();
-	if (threadIdx.x < kIcpAcc) {
-		float s = red[0][threadIdx.x];
-#pragma unroll
-		for (int x = 1; x < kIcpThreads / 64; x++) s += red[x][threadIdx.x];
-		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = s;
-	}
-}
-
-// ---- four queries per wavefront (K = 2 hierarchies, i.e. up to 65 536 target points) ------------------
-// The wave-per-query pass above is instruction-issue bound (~1250 wave-instructions per query, most
-// of them the scalar ballot-walking loops).  Here a wavefront is four 16-lane rows; each row owns one
-// query, each lane four of the 64 children of the current group, and a leaf's 16 slots map onto the
-// row's 16 lanes.  Minima inside a row are DPP butterflies (quad_perm, row_half_mirror, row_mirror):
-// no scalar loops, no LDS, four queries per issued instruction.  Rows are at different stages of
-// their walks, so one loop iteration runs (at most) the two step kinds "enter the nearest pending
-// group" and "scan the nearest pending leaf" under the rows' exec masks.  Same exactness argument.
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v)
 {
@@ -708,110 +561,147 @@ __device__ __forceinline__ int row_pick(const float lb[4], unsigned pend, int l,
 	return 4 * wl + j;
 }
 
-template <int LAYOUT>
-__global__ __launch_bounds__(kIcpThreads) void icp_pass_rows_kernel(const float4* __restrict__ src, int N,
-                                                                    const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
-                                                                    float* __restrict__ partials)
+// Exact 1-NN of the row's query.  `active` rows walk; the others idle through the loop.  On return
+// best/idx are uniform in the row and exactly one lane of an active row has `mine` set: the one whose
+// leaf slot holds the neighbour (its coordinates and slot ride along in that lane).
+struct RowNn { float best; int idx; bool mine; float mx, my, mz; int slot; };
+
+template <int K, int LAYOUT>
+__device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt, const Box6x4& rootb, int l, int row,
+                                              float qx, float qy, float qz, bool active)
 {
-	__shared__ float red[kIcpThreads / 64][kIcpAcc];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
-	const int w = blockIdx.x * (kIcpThreads / 64) + wave;
-	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
-	const int i = w * 4 + row;
-	const bool valid = i < N;
-	const float4 p = src[valid ? i : N - 1];
-	if (st->converged) return;
-	float acc[kIcpAcc];
+	float lb[K][4];
+	unsigned pend[K];
+	int node[K];                              // group index at each level; leaves of level K-1 are node*64 + c
+	node[0] = 0;
+	boxes_lb4(rootb, qx, qy, qz, lb[0]);
+	pend[0] = 0xFu;
 #pragma unroll
-	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
-	{
-		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-		// The child of the root with the smallest box distance always survives any bound (the true
-		// neighbour's child has lb <= d_nn), so its boxes are fetched together with the DT seed
-		// instead of after it: one dependent memory round trip less.
-		float lb0[4], lb1[4];
-		boxes_lb4(rootb, qx, qy, qz, lb0);
-		unsigned pend0 = 0xFu, pend1 = 0;
-		int group = row_pick(lb0, pend0, l, row, pend0);
-		const Box6x4 fb = load_child_boxes4(kd.boxes[1] + (size_t)group * 384, l);
-		float best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
-		int bidx = INT_MAX;
-		bool mine = false;                        // this lane holds the row's current nearest point
-		float mx = 0.f, my = 0.f, mz = 0.f;
-		boxes_lb4(fb, qx, qy, qz, lb1);
+	for (int L = 1; L < K; L++) {
+		pend[L] = 0u; node[L] = 0;
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			if (!(lb0[j] <= best)) pend0 &= ~(1u << j);
-			pend1 |= (lb1[j] <= best ? 1u : 0u) << j;
+		for (int j = 0; j < 4; j++) lb[L][j] = 0.f;
+	}
+	// The child of the root with the smallest box distance survives any valid bound (the true
+	// neighbour's child has lb <= d_nn), so its boxes are fetched together with the DT seed instead
+	// of after it: one dependent memory round trip less.
+	Box6x4 fb = rootb;
+	if constexpr (K > 1) {
+		node[1] = row_pick(lb[0], pend[0], l, row, pend[0]);
+		fb = load_child_boxes4(kd.boxes[1] + (size_t)node[1] * 384, l);
+	}
+	RowNn r{nn_upper_bound<LAYOUT>(dt, qx, qy, qz), INT_MAX, false, 0.f, 0.f, 0.f, 0};
+	int d = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		if (!(lb[0][j] <= r.best)) pend[0] &= ~(1u << j);
+	if constexpr (K > 1) {
+		boxes_lb4(fb, qx, qy, qz, lb[1]);
+#pragma unroll
+		for (int j = 0; j < 4; j++) pend[1] |= (lb[1][j] <= r.best ? 1u : 0u) << j;
+		d = 1;
+	}
+	bool done = !active;
+	while (__any(!done)) {
+		// leave exhausted levels (branch-free; a row is 16 whole lanes, so the ballot slices are exact)
+#pragma unroll
+		for (int L = K - 1; L >= 1; L--) {
+			const bool any = ((unsigned)(__ballot(pend[L] != 0u) >> (16 * row)) & 0xffffu) != 0u;
+			if (d == L && !any) d = L - 1;
 		}
-		bool done = !valid;
-		while (__any(!done)) {
-			const bool has1 = ((unsigned)(__ballot(pend1 != 0u) >> (16 * row)) & 0xffffu) != 0u;
-			if (!done && has1) {
-				// ---- scan the two nearest pending leaves of the current group: one slot per lane each ----
-				const int ca = row_pick(lb1, pend1, l, row, pend1);
-				const int cb = row_pick(lb1, pend1, l, row, pend1);
-				const float4 pa = kd.pts[(group * 64 + ca) * kLeafSlots + l];
-				float4 pt = kd.pts[(group * 64 + (cb < 0 ? ca : cb)) * kLeafSlots + l];
-				float d, e;
-				{
-					const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
-					d = d0 * d0;                                     // L2_Simple_Adaptor accumulation order
-					d += d1 * d1;
-					d += d2 * d2;
-					const float e0 = qx - pt.x, e1 = qy - pt.y, e2 = qz - pt.z;
-					e = e0 * e0;
-					e += e1 * e1;
-					e += e2 * e2;
-				}
-				if (d < e || (d == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = d; }
-				const unsigned db = __float_as_uint(e);
-				const unsigned dmin = row_min_u32(db);
-				const unsigned id = (unsigned)__float_as_int(pt.w);
-				const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);      // ties -> lowest original index
-				const float dm = __uint_as_float(dmin);
-				if (dm < best || (dm == best && (int)idmin < bidx)) {
-					best = dm;
-					bidx = (int)idmin;
-					mine = db == dmin && id == idmin;
-					mx = pt.x; my = pt.y; mz = pt.z;
-				}
+		{
+			const bool any = ((unsigned)(__ballot(pend[0] != 0u) >> (16 * row)) & 0xffffu) != 0u;
+			if (d == 0 && !any) done = true;
+		}
+		if (done) continue;
+		if (d == K - 1) {
+			// ---- scan the two nearest pending leaves of the current group: one slot per lane each ----
+			const int ca = row_pick(lb[K - 1], pend[K - 1], l, row, pend[K - 1]);
+			const int cb = row_pick(lb[K - 1], pend[K - 1], l, row, pend[K - 1]);
+			const int sa = (node[K - 1] * 64 + ca) * kLeafSlots + l;
+			int sb = (node[K - 1] * 64 + (cb < 0 ? ca : cb)) * kLeafSlots + l;
+			const float4 pa = kd.pts[sa];
+			float4 pt = kd.pts[sb];
+			const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
+			float da = d0 * d0;                                  // L2_Simple_Adaptor accumulation order
+			da += d1 * d1;
+			da += d2 * d2;
+			const float e0 = qx - pt.x, e1 = qy - pt.y, e2 = qz - pt.z;
+			float e = e0 * e0;
+			e += e1 * e1;
+			e += e2 * e2;
+			if (da < e || (da == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = da; sb = sa; }
+			const unsigned db = __float_as_uint(e);
+			const unsigned dmin = row_min_u32(db);
+			const unsigned id = (unsigned)__float_as_int(pt.w);
+			const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);      // ties -> lowest original index
+			const float dm = __uint_as_float(dmin);
+			if (dm < r.best || (dm == r.best && (int)idmin < r.idx)) {
+				r.best = dm;
+				r.idx = (int)idmin;
+				r.mine = db == dmin && id == idmin;
+				r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = sb;
+			}
 #pragma unroll
-				for (int j = 0; j < 4; j++) {                        // re-filter with the improved bound
-					if (!(lb1[j] <= best)) pend1 &= ~(1u << j);
-					if (!(lb0[j] <= best)) pend0 &= ~(1u << j);
-				}
-			} else if (!done) {
-				// ---- enter the nearest pending group of the root (or finish) ----
-				const int c = row_pick(lb0, pend0, l, row, pend0);
-				if (c < 0) {
-					done = true;
-				} else {
-					group = c;
-					const Box6x4 cb = load_child_boxes4(kd.boxes[1] + (size_t)group * 384, l);
-					boxes_lb4(cb, qx, qy, qz, lb1);
-					pend1 = 0;
+			for (int L = 0; L < K; L++)                          // re-filter every level with the improved bound
 #pragma unroll
-					for (int j = 0; j < 4; j++) pend1 |= (lb1[j] <= best ? 1u : 0u) << j;
+				for (int j = 0; j < 4; j++)
+					if (!(lb[L][j] <= r.best)) pend[L] &= ~(1u << j);
+		} else {
+			// ---- enter the nearest pending child group one level down ----
+			const int d_in = d;
+#pragma unroll
+			for (int L = 0; L + 1 < K; L++) {
+				if (d_in == L) {
+					const int NL = L + 1;
+					const int c = row_pick(lb[L], pend[L], l, row, pend[L]);
+					node[NL] = node[L] * 64 + c;
+					const Box6x4 cb = load_child_boxes4(kd.boxes[NL] + (size_t)node[NL] * 384, l);
+					boxes_lb4(cb, qx, qy, qz, lb[NL]);
+					pend[NL] = 0u;
+#pragma unroll
+					for (int j = 0; j < 4; j++) pend[NL] |= (lb[NL][j] <= r.best ? 1u : 0u) << j;
+					d = NL;
 				}
 			}
 		}
-		if (valid && mine) {                          // exactly one lane of the row
-			const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];
-			const float bx = mx - st->cm[0], by = my - st->cm[1], bz = mz - st->cm[2];
-			acc[0] += ax; acc[1] += ay; acc[2] += az;
-			acc[3] += bx; acc[4] += by; acc[5] += bz;
-			acc[6] += ax * bx; acc[7] += ax * by; acc[8] += ax * bz;
-			acc[9] += ay * bx; acc[10] += ay * by; acc[11] += ay * bz;
-			acc[12] += az * bx; acc[13] += az * by; acc[14] += az * bz;
-			acc[15] += best;
-		}
+	}
+	return r;
+}
+
+template <int K, int LAYOUT>
+__global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
+                                                               const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
+                                                               float* __restrict__ partials)
+{
+	__shared__ float red[kIcpThreads / 64][kIcpAcc];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
+	const int i = (blockIdx.x * (kIcpThreads / 64) + wave) * 4 + row;
+	const bool valid = i < N;
+	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
+	const float4 p = src[valid ? i : N - 1];
+	if (st->converged) return;                                   // loop already finished: queued launches drain
+	// jly_icp3d.hpp:222-224, left-to-right float sums
+	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+	const RowNn r = rows_nearest<K, LAYOUT>(kd, dt, rootb, l, row, qx, qy, qz, valid);
+	float acc[kIcpAcc];
+#pragma unroll
+	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
+	if (valid && r.mine) {                                       // exactly one lane of the row
+		const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
+		const float bx = r.mx - st->cm[0], by = r.my - st->cm[1], bz = r.mz - st->cm[2];
+		acc[0] = ax; acc[1] = ay; acc[2] = az;
+		acc[3] = bx; acc[4] = by; acc[5] = bz;
+		acc[6] = ax * bx; acc[7] = ax * by; acc[8] = ax * bz;
+		acc[9] = ay * bx; acc[10] = ay * by; acc[11] = ay * bz;
+		acc[12] = az * bx; acc[13] = az * by; acc[14] = az * bz;
+		acc[15] = r.best;
 	}
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) {
-		float v = row_sum_f32(acc[k]);                // fixed butterfly order: deterministic
+		float v = row_sum_f32(acc[k]);                           // fixed butterfly order: deterministic
 		v += __shfl_xor(v, 16, 64);
 		v += __shfl_xor(v, 32, 64);
 		if (lane == 0) red[wave][k] = v;
@@ -832,20 +722,17 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const float4* __res
                                                              const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                              float* __restrict__ nn_d2, int* __restrict__ nn_slot)
 {
+	const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
+	const int i = (blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6)) * 4 + row;
+	const bool valid = i < N;
+	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);
+	const float4 p = src[valid ? i : N - 1];
 	if (st->converged) return;
-	const int lane = threadIdx.x & 63;
-	const int w = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);
-	const Box6 rootbox = load_child_box(kd.boxes[0], lane);
-	for (int j = 0; j < kIcpQueriesPerWave; j++) {
-		const int i = w * kIcpQueriesPerWave + j;
-		if (i >= N) break;
-		const float4 p = src[i];
-		const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-		const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-		const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-		const NnResult r = wave_nearest<K>(kd, rootbox, lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
-		if (lane == 0) { nn_d2[i] = r.best; nn_slot[i] = r.slot; }
-	}
+	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
+	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
+	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
+	const RowNn r = rows_nearest<K, LAYOUT>(kd, dt, rootb, l, row, qx, qy, qz, valid);
+	if (valid && r.mine) { nn_d2[i] = r.best; nn_slot[i] = r.slot; }
 }
 
 // one workgroup: key of the num-th smallest d2 (3-digit radix select), then inclusion flags with the
@@ -952,12 +839,15 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 					aqq += B[3 * i + q] * B[3 * i + q];
 					apq += B[3 * i + p] * B[3 * i + q];
 				}
-				// columns orthogonal to 1e-14 relative: the rotation is returned in float (6e-8)
-				if (apq == 0.0 || apq * apq <= 1e-28 * (app * aqq)) continue;
+				// columns orthogonal to 1e-12 relative: the rotation is returned in float (6e-8)
+				if (apq == 0.0 || apq * apq <= 1e-24 * (app * aqq)) continue;
 				rotated = true;
-				const double zeta = (aqq - app) / (2 * apq);
-				const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-				const double cs = 1 / sqrt(1 + tn * tn), sn = cs * tn;
+				// tan(theta) = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq - app) / (2 apq), written
+				// with one square root, one division and one reciprocal square root: this lane is the
+				// serial tail of every ICP iteration and fp64 div / sqrt are ~200-cycle sequences
+				const double da = aqq - app, db = 2 * apq;
+				const double tn = (da >= 0 ? db : -db) / (fabs(da) + sqrt(da * da + db * db));
+				const double cs = rsqrt(1 + tn * tn), sn = cs * tn;
 				for (int i = 0; i < 3; i++) {
 					const double bp = B[3 * i + p], bq = B[3 * i + q];
 					B[3 * i + p] = cs * bp - sn * bq;
@@ -970,9 +860,10 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 		if (!rotated) break;
 	}
 	for (int j = 0; j < 3; j++) {
-		const double n = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
-		W[j] = n;
-		for (int i = 0; i < 3; i++) U[3 * i + j] = n > 0 ? B[3 * i + j] / n : 0.0;
+		const double n2 = B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j];
+		const double rn = n2 > 0 ? rsqrt(n2) : 0.0;
+		W[j] = n2 * rn;
+		for (int i = 0; i < 3; i++) U[3 * i + j] = B[3 * i + j] * rn;
 	}
 	for (int j = 0; j < 3; j++) {          // rank-2 input: complete the missing left vector
 		if (W[j] > 1e-200) continue;
@@ -1112,7 +1003,7 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 
 int icp_blocks(int N)
 {
-	const int per_block = (kIcpThreads / 64) * kIcpQueriesPerWave;
+	const int per_block = (kIcpThreads / 64) * 4;      // four queries per wavefront
 	return (N + per_block - 1) / per_block;
 }
 
@@ -1147,28 +1038,9 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 	return hipGetLastError();
 }
 
-// GOICP_ICP_ROWS=0 forces the wavefront-per-query pass for K = 2 as well (A/B runs, tests)
-static bool icp_rows_enabled()
-{
-	const char* e = getenv("GOICP_ICP_ROWS");
-	return !(e && e[0] == '0');
-}
-int icp_rows_blocks(int N)
-{
-	const int per_block = (kIcpThreads / 64) * 4;
-	return (N + per_block - 1) / per_block;
-}
-
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
                                 hipStream_t stream)
 {
-	if (kd.K == 2 && icp_rows_enabled()) {
-		const dim3 grid(icp_rows_blocks(N)), block(kIcpThreads);
-		if (dt.layout) hipLaunchKernelGGL(icp_pass_rows_kernel<1>, grid, block, 0, stream, src, N, st, kd, dt, partials);
-		else hipLaunchKernelGGL(icp_pass_rows_kernel<0>, grid, block, 0, stream, src, N, st, kd, dt, partials);
-		hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, icp_rows_blocks(N), st);
-		return hipGetLastError();
-	}
 	if (kd.K == 1) launch_pass_k<1>(src, N, st, kd, dt, partials, stream);
 	else if (kd.K == 2) launch_pass_k<2>(src, N, st, kd, dt, partials, stream);
 	else launch_pass_k<3>(src, N, st, kd, dt, partials, stream);
@@ -1198,18 +1070,19 @@ template <int K, int LAYOUT>
 __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, DtDesc dt,
                                                                int32_t* __restrict__ idx, float* __restrict__ d2)
 {
-	const int lane = threadIdx.x & 63;
-	const int i = blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6);   // one wavefront per query
-	if (i >= n) return;
-	const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-	const NnResult r = wave_nearest<K>(kd, load_child_box(kd.boxes[0], lane), lane, qx, qy, qz, nn_upper_bound<LAYOUT>(dt, qx, qy, qz));
-	if (lane == 0) { idx[i] = r.idx; d2[i] = r.best; }
+	const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
+	const int i = (blockIdx.x * (kIcpThreads / 64) + (threadIdx.x >> 6)) * 4 + row;   // one 16-lane row per query
+	const bool valid = i < n;
+	const int iq = valid ? i : n - 1;
+	const float qx = q[3 * iq], qy = q[3 * iq + 1], qz = q[3 * iq + 2];
+	const RowNn r = rows_nearest<K, LAYOUT>(kd, dt, load_child_boxes4(kd.boxes[0], l), l, row, qx, qy, qz, valid);
+	if (valid && r.mine) { idx[i] = r.idx; d2[i] = r.best; }
 }
 
 template <int K>
 static void launch_nn_k(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
 {
-	const dim3 grid((n + kIcpThreads / 64 - 1) / (kIcpThreads / 64)), block(kIcpThreads);
+	const dim3 grid(icp_blocks(n)), block(kIcpThreads);
 	if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<K, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 	else hipLaunchKernelGGL((nn_query_kernel<K, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 }

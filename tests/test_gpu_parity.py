@@ -235,12 +235,9 @@ def test_nn_three_level_hierarchy(pkg, oracle_mod):
     reg.close()
 
 
-@pytest.mark.parametrize("rows", ["1", "0"])
-def test_icp_run_golden(pkg, reg10, monkeypatch, rows):
+def test_icp_run_golden(pkg, reg10):
     """IterativeClosestPoint3D::run / ICP3D::Run with forced iteration counts: 1e-4 abs on R,t for
-    <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3.  Both correspondence-pass kernels:
-    four queries per wavefront (default for two-level hierarchies) and one query per wavefront."""
-    monkeypatch.setenv("GOICP_ICP_ROWS", rows)
+    <= 10 iterations, 1e-3 for the converged runs; err rel 1e-3."""
     g = golden("icp_iter")
     for c in g["cases"]:
         icp = pkg.IterativeClosestPoint3D(reg10, c["max_iter"], c["err_diff"], c["R0"], c["t0"])
@@ -253,10 +250,8 @@ def test_icp_run_golden(pkg, reg10, monkeypatch, rows):
             assert icp.iters == c["max_iter"]
 
 
-@pytest.mark.parametrize("rows", ["1", "0"])
-def test_icp_first_pass_error_is_bruteforce_nn_sum(pkg, oracle_mod, bunny_model, bunny_data10, monkeypatch, rows):
+def test_icp_first_pass_error_is_bruteforce_nn_sum(pkg, oracle_mod, bunny_model, bunny_data10):
     """The correspondence pass is exact: its error equals the brute-force nearest-neighbour sum."""
-    monkeypatch.setenv("GOICP_ICP_ROWS", rows)
     reg = pkg.Registration(bunny_model, bunny_data10, 1e-3)
     _, d2 = oracle_mod.nn_brute(bunny_model, bunny_data10)
     err = reg.icp_step().best_sse

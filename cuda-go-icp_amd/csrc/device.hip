@@ -541,24 +541,36 @@ __device__ __forceinline__ void boxes_lb4(const Box6x4& b, float qx, float qy, f
 	lb[2] = box_lb1(b.lox.z, b.loy.z, b.loz.z, b.hix.z, b.hiy.z, b.hiz.z, qx, qy, qz);
 	lb[3] = box_lb1(b.lox.w, b.loy.w, b.loz.w, b.hix.w, b.hiy.w, b.hiz.w, qx, qy, qz);
 }
-// nearest pending child of the row: key = distance bits with the two low mantissa bits replaced by the
-// child's sub-index (ordering only), row minimum, owner lane from the ballot.  Returns the child 0..63 or -1.
-__device__ __forceinline__ int row_pick(const float lb[4], unsigned pend, int l, int row, unsigned& pend_out)
+// A child is held as one sortable key: the bits of its box distance (>= 0, so they order like the
+// float) with the two low mantissa bits replaced by the child's sub-index 0..3; 0xffffffff once taken.
+// Pruning with (key & ~3) <= bits(best) is conservative by at most those two bits (a child that could
+// just have been skipped is visited): exactness is untouched.
+__device__ __forceinline__ void boxes_keys4(const Box6x4& b, float qx, float qy, float qz, unsigned key[4])
 {
-	unsigned key = 0xffffffffu;
+	float lb[4];
+	boxes_lb4(b, qx, qy, qz, lb);
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
-		const unsigned k = (__float_as_uint(lb[j]) & ~3u) | (unsigned)j;
-		key = ((pend >> j) & 1u) ? min(key, k) : key;
-	}
-	const unsigned m = row_min_u32(key);
-	const unsigned owners = (unsigned)(__ballot(key == m && m != 0xffffffffu) >> (16 * row)) & 0xffffu;
-	pend_out = pend;
-	if (m == 0xffffffffu) return -1;
+	for (int j = 0; j < 4; j++) key[j] = (__float_as_uint(lb[j]) & ~3u) | (unsigned)j;
+}
+// Take the nearest remaining child of the row: returns its key (uniform in the row; 0xffffffff when
+// none is left) and the child 0..63; the owner lane marks it taken.  Because children are taken in
+// ascending order, "key above the best distance" means the whole group is exhausted: no pending
+// masks, no re-filtering.
+__device__ __forceinline__ unsigned row_take(unsigned key[4], int l, int row, int& child)
+{
+	const unsigned mine = min(min(key[0], key[1]), min(key[2], key[3]));
+	const unsigned m = row_min_u32(mine);
+	const unsigned owners = (unsigned)(__ballot(mine == m) >> (16 * row)) & 0xffffu;
 	const int wl = __ffs((int)owners) - 1;
-	const int j = (int)(m & 3u);
-	if (l == wl) pend_out = pend & ~(1u << j);
-	return 4 * wl + j;
+	const unsigned j = m & 3u;
+	if (l == wl) {
+		key[0] = j == 0u ? 0xffffffffu : key[0];
+		key[1] = j == 1u ? 0xffffffffu : key[1];
+		key[2] = j == 2u ? 0xffffffffu : key[2];
+		key[3] = j == 3u ? 0xffffffffu : key[3];
+	}
+	child = 4 * wl + (int)j;
+	return m;
 }
 
 // Exact 1-NN of the row's query.  `active` rows walk; the others idle through the loop.  On return
@@ -570,102 +582,85 @@ template <int K, int LAYOUT>
 __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt, const Box6x4& rootb, int l, int row,
                                               float qx, float qy, float qz, bool active)
 {
-	float lb[K][4];
-	unsigned pend[K];
+	unsigned key[K][4];
 	int node[K];                              // group index at each level; leaves of level K-1 are node*64 + c
 	node[0] = 0;
-	boxes_lb4(rootb, qx, qy, qz, lb[0]);
-	pend[0] = 0xFu;
+	boxes_keys4(rootb, qx, qy, qz, key[0]);
 #pragma unroll
 	for (int L = 1; L < K; L++) {
-		pend[L] = 0u; node[L] = 0;
+		node[L] = 0;
 #pragma unroll
-		for (int j = 0; j < 4; j++) lb[L][j] = 0.f;
+		for (int j = 0; j < 4; j++) key[L][j] = 0xffffffffu;
 	}
 	// The child of the root with the smallest box distance survives any valid bound (the true
 	// neighbour's child has lb <= d_nn), so its boxes are fetched together with the DT seed instead
 	// of after it: one dependent memory round trip less.
 	Box6x4 fb = rootb;
 	if constexpr (K > 1) {
-		node[1] = row_pick(lb[0], pend[0], l, row, pend[0]);
+		row_take(key[0], l, row, node[1]);
 		fb = load_child_boxes4(kd.boxes[1] + (size_t)node[1] * 384, l);
 	}
 	RowNn r{nn_upper_bound<LAYOUT>(dt, qx, qy, qz), INT_MAX, false, 0.f, 0.f, 0.f, 0};
+	unsigned bbits = __float_as_uint(r.best);
 	int d = 0;
-#pragma unroll
-	for (int j = 0; j < 4; j++)
-		if (!(lb[0][j] <= r.best)) pend[0] &= ~(1u << j);
 	if constexpr (K > 1) {
-		boxes_lb4(fb, qx, qy, qz, lb[1]);
-#pragma unroll
-		for (int j = 0; j < 4; j++) pend[1] |= (lb[1][j] <= r.best ? 1u : 0u) << j;
+		boxes_keys4(fb, qx, qy, qz, key[1]);
 		d = 1;
 	}
 	bool done = !active;
 	while (__any(!done)) {
-		// leave exhausted levels (branch-free; a row is 16 whole lanes, so the ballot slices are exact)
+		// One step per row and iteration: leave exhausted levels (cascading through the unrolled
+		// blocks below), then either enter the nearest child group or scan the two nearest leaves.
+		bool acted = done;
 #pragma unroll
-		for (int L = K - 1; L >= 1; L--) {
-			const bool any = ((unsigned)(__ballot(pend[L] != 0u) >> (16 * row)) & 0xffffu) != 0u;
-			if (d == L && !any) d = L - 1;
-		}
-		{
-			const bool any = ((unsigned)(__ballot(pend[0] != 0u) >> (16 * row)) & 0xffffu) != 0u;
-			if (d == 0 && !any) done = true;
-		}
-		if (done) continue;
-		if (d == K - 1) {
-			// ---- scan the two nearest pending leaves of the current group: one slot per lane each ----
-			const int ca = row_pick(lb[K - 1], pend[K - 1], l, row, pend[K - 1]);
-			const int cb = row_pick(lb[K - 1], pend[K - 1], l, row, pend[K - 1]);
-			const int sa = (node[K - 1] * 64 + ca) * kLeafSlots + l;
-			int sb = (node[K - 1] * 64 + (cb < 0 ? ca : cb)) * kLeafSlots + l;
-			const float4 pa = kd.pts[sa];
-			float4 pt = kd.pts[sb];
-			const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
-			float da = d0 * d0;                                  // L2_Simple_Adaptor accumulation order
-			da += d1 * d1;
-			da += d2 * d2;
-			const float e0 = qx - pt.x, e1 = qy - pt.y, e2 = qz - pt.z;
-			float e = e0 * e0;
-			e += e1 * e1;
-			e += e2 * e2;
-			if (da < e || (da == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = da; sb = sa; }
-			const unsigned db = __float_as_uint(e);
-			const unsigned dmin = row_min_u32(db);
-			const unsigned id = (unsigned)__float_as_int(pt.w);
-			const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);      // ties -> lowest original index
-			const float dm = __uint_as_float(dmin);
-			if (dm < r.best || (dm == r.best && (int)idmin < r.idx)) {
-				r.best = dm;
-				r.idx = (int)idmin;
-				r.mine = db == dmin && id == idmin;
-				r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = sb;
-			}
-#pragma unroll
-			for (int L = 0; L < K; L++)                          // re-filter every level with the improved bound
-#pragma unroll
-				for (int j = 0; j < 4; j++)
-					if (!(lb[L][j] <= r.best)) pend[L] &= ~(1u << j);
-		} else {
-			// ---- enter the nearest pending child group one level down ----
-			const int d_in = d;
-#pragma unroll
-			for (int L = 0; L + 1 < K; L++) {
-				if (d_in == L) {
-					const int NL = L + 1;
-					const int c = row_pick(lb[L], pend[L], l, row, pend[L]);
+		for (int L = K - 1; L >= 0; L--) {
+			if (!acted && d == L) {
+				int c;
+				const unsigned m = row_take(key[L], l, row, c);
+				if ((m & ~3u) > bbits) {                             // nothing left within the best distance
+					if (L == 0) { done = true; acted = true; }
+					else d = L - 1;
+				} else if (L == K - 1) {
+					// ---- scan the two nearest remaining leaves of the group: one slot per lane each ----
+					int c2;
+					const unsigned m2 = row_take(key[L], l, row, c2);
+					const int sa = (node[L] * 64 + c) * kLeafSlots + l;
+					int sb = (node[L] * 64 + ((m2 & ~3u) > bbits ? c : c2)) * kLeafSlots + l;
+					const float4 pa = kd.pts[sa];
+					float4 pt = kd.pts[sb];
+					const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
+					float da = d0 * d0;                              // L2_Simple_Adaptor accumulation order
+					da += d1 * d1;
+					da += d2 * d2;
+					const float e0 = qx - pt.x, e1 = qy - pt.y, e2 = qz - pt.z;
+					float e = e0 * e0;
+					e += e1 * e1;
+					e += e2 * e2;
+					if (da < e || (da == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = da; sb = sa; }
+					const unsigned db = __float_as_uint(e);
+					const unsigned dmin = row_min_u32(db);
+					const unsigned id = (unsigned)__float_as_int(pt.w);
+					const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);   // ties -> lowest original index
+					if (dmin < bbits || (dmin == bbits && (int)idmin < r.idx)) {
+						bbits = dmin;
+						r.idx = (int)idmin;
+						r.mine = db == dmin && id == idmin;
+						r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = sb;
+					}
+					acted = true;
+				} else {
+					// ---- enter the nearest remaining child group one level down ----
+					const int NL = L + 1 < K ? L + 1 : L;
 					node[NL] = node[L] * 64 + c;
 					const Box6x4 cb = load_child_boxes4(kd.boxes[NL] + (size_t)node[NL] * 384, l);
-					boxes_lb4(cb, qx, qy, qz, lb[NL]);
-					pend[NL] = 0u;
-#pragma unroll
-					for (int j = 0; j < 4; j++) pend[NL] |= (lb[NL][j] <= r.best ? 1u : 0u) << j;
+					boxes_keys4(cb, qx, qy, qz, key[NL]);
 					d = NL;
+					acted = true;
 				}
 			}
 		}
 	}
+	r.best = __uint_as_float(bbits);
 	return r;
 }
 

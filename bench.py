@@ -218,11 +218,11 @@ def main():
         # were collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and
         # WRITE_SIZE, gfx950 x2 correction on FETCH_SIZE) and are committed under profiles/
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_bounds.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_bounds.json")
         if args.workload == "bunny" and args.dt_size == 300 and Bc == 65536 and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_c_pmc_bounds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; fabric-side of L2, includes Infinity-Cache hits)"
+            traffic_src = "profiles/r01_e_pmc_bounds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; fabric-side of L2, includes Infinity-Cache hits)"
         roofline = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,

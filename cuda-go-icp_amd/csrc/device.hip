@@ -9,8 +9,8 @@
 //                        16 B (ub pass) / 20 B (lb pass) algorithmic per point; sibling fast path.
 //   bounds_finalize      fixed-order sum of the per-chunk partials (deterministic, no float atomics)
 //   bounds_trim_kernel   trimmed form: exact k-th smallest residual per cube by radix select
-//   icp_pass_kernel      (b) one ICP correspondence pass: transform, exact 1-NN (one wavefront per
-//                        query over a 64-ary box hierarchy, DT-seeded bound), pivoted sums
+//   icp_pass_kernel      (b) one ICP correspondence pass: transform, exact 1-NN (four queries per
+//                        wavefront over a 64-ary box hierarchy, DT-seeded bound), pivoted sums
 //   icp_finalize_update  fixed-order double-precision reduction + the rest of the ICP loop body
 //                        (convergence test, SVD, pose update) on the device-resident state
 //   icp_nn/select/accum  trimmed ICP: NN of every point, radix select of the num nearest, sums
@@ -20,7 +20,6 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cmath>
-#include <cstdlib>
 
 #include "device.hpp"
 

@@ -217,6 +217,27 @@ def test_nn_vs_bruteforce(reg10, oracle_mod, bunny_model):
     assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
 
 
+@pytest.mark.parametrize("side", [6, 14])
+def test_nn_ties_on_a_lattice(pkg, oracle_mod, side):
+    """Lattice target (side^3 points: one- and two-level hierarchies) with duplicated points, queries at
+    cell centres / face centres / lattice points: 8-, 4-, 2-way and duplicate ties must all resolve to the
+    lowest original index, exactly as a brute-force scan does."""
+    g = (np.arange(side, dtype=np.float32) - (side - 1) / 2) * np.float32(0.125)       # exactly representable
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(side)
+    target = np.concatenate([lat, lat[rng.integers(0, len(lat), len(lat) // 4)]])       # duplicates
+    target = target[rng.permutation(len(target))].astype(np.float32)
+    src = lat[:64].copy()
+    reg = pkg.Registration(target, src, 1e-3, dt_size=64)
+    h = np.float32(0.0625)
+    q = np.concatenate([lat[:400] + h, lat[:400] + np.array([h, h, 0], np.float32),
+                        lat[:400] + np.array([h, 0, 0], np.float32), lat[:400]]).astype(np.float32)
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    reg.close()
+
+
 def test_nn_three_level_hierarchy(pkg, oracle_mod):
     """M = 120 000 > 64*64*16 exercises the K = 3 box hierarchy (BASELINE configs[2]/[4] sizes): exact vs
     brute force, including queries far outside the cloud and outside the DT grid."""

@@ -81,6 +81,16 @@ __device__ __forceinline__ int voxel_fast(float q, float mn, float scale, float 
 	return (int)F;
 }
 
+// reference expression (jly_3ddt.cpp:984-986), taken by the few lanes in 10^4 whose float index is not
+// provably right.  The empty asm keeps the caller's `if (risky)` a real branch: left to itself the
+// compiler if-converts it and puts the five fp64 instructions of every index on every lane (measured:
+// 30 of the 255 VALU instructions per point of the sibling path, at half rate).
+__device__ __forceinline__ int voxel_exact(float q, double mn, double scale)
+{
+	__asm__ volatile("");
+	return (int)(((double)q - mn) * scale + 0.5);
+}
+
 template <int LAYOUT>
 __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float qy, float qz)
 {
@@ -90,9 +100,9 @@ __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float q
 	int z = voxel_fast(qz, dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
 	if (risky) {
 		// double index math exactly as the reference: (x - xMin)*scale + 0.5, truncate
-		x = (int)(((double)qx - dt.xmin) * dt.scale + 0.5);
-		y = (int)(((double)qy - dt.ymin) * dt.scale + 0.5);
-		z = (int)(((double)qz - dt.zmin) * dt.scale + 0.5);
+		x = voxel_exact(qx, dt.xmin, dt.scale);
+		y = voxel_exact(qy, dt.ymin, dt.scale);
+		z = voxel_exact(qz, dt.zmin, dt.scale);
 	}
 	const int V = dt.V;
 	if ((unsigned)x < (unsigned)V && (unsigned)y < (unsigned)V && (unsigned)z < (unsigned)V)
@@ -115,15 +125,8 @@ __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float q
 // so one unsigned compare of the sum tells whether the fast fetch is valid.
 constexpr unsigned kOutside = 0x40000000u;
 template <int LAYOUT, int AXIS>
-__device__ __forceinline__ unsigned axis_term(const DtDesc& dt, float q)
+__device__ __forceinline__ unsigned axis_offset(const DtDesc& dt, int i)
 {
-	const float mn_f = AXIS == 0 ? dt.xmin_f : (AXIS == 1 ? dt.ymin_f : dt.zmin_f);
-	bool risky = false;
-	int i = voxel_fast(q, mn_f, dt.scale_f, dt.c1, dt.c2, risky);
-	if (risky) {
-		const double mn = AXIS == 0 ? dt.xmin : (AXIS == 1 ? dt.ymin : dt.zmin);
-		i = (int)(((double)q - mn) * dt.scale + 0.5);
-	}
 	if ((unsigned)i >= (unsigned)dt.V) return kOutside;
 	const unsigned u = (unsigned)i;
 	if (LAYOUT == 0) return AXIS == 0 ? u : (AXIS == 1 ? __umul24(u, (unsigned)dt.V) : __umul24(u, (unsigned)(dt.V * dt.V)));
@@ -196,9 +199,25 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 			const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
 			const float rho = coeff * p.w;
 			const float qx[2] = {rx + tx0, rx + tx1}, qy[2] = {ry + ty0, ry + ty1}, qz[2] = {rz + tz0, rz + tz1};
-			const unsigned fx[2] = {axis_term<LAYOUT, 0>(dt, qx[0]), axis_term<LAYOUT, 0>(dt, qx[1])};
-			const unsigned fy[2] = {axis_term<LAYOUT, 1>(dt, qy[0]), axis_term<LAYOUT, 1>(dt, qy[1])};
-			const unsigned fz[2] = {axis_term<LAYOUT, 2>(dt, qz[0]), axis_term<LAYOUT, 2>(dt, qz[1])};
+			bool risky = false;
+			int ix[2], iy[2], iz[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				ix[k] = voxel_fast(qx[k], dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+				iy[k] = voxel_fast(qy[k], dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
+				iz[k] = voxel_fast(qz[k], dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+			}
+			if (risky) {
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+				}
+			}
+			const unsigned fx[2] = {axis_offset<LAYOUT, 0>(dt, ix[0]), axis_offset<LAYOUT, 0>(dt, ix[1])};
+			const unsigned fy[2] = {axis_offset<LAYOUT, 1>(dt, iy[0]), axis_offset<LAYOUT, 1>(dt, iy[1])};
+			const unsigned fz[2] = {axis_offset<LAYOUT, 2>(dt, iz[0]), axis_offset<LAYOUT, 2>(dt, iz[1])};
 #pragma unroll
 			for (int c = 0; c < kGroup; c++) {
 				const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];

@@ -115,11 +115,11 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		rot_coeff_[l] = 2 * std::sin(maxAngle / 2);
 	}
 
-	// ---- source cloud: (x,y,z,|p|), Morton order ----
+	// ---- source cloud: (x,y,z,|p|), ordered for gather locality (morton_sort: 0 input order, 1 Morton curve, 2 k-d clusters) ----
 	{
 		std::vector<int32_t> perm(N_);
 		for (size_t i = 0; i < N_; i++) perm[i] = (int32_t)i;
-		if (p_.morton_sort) {
+		if (p_.morton_sort == 1) {
 			float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 			for (size_t i = 0; i < N_; i++)
 				for (int k = 0; k < 3; k++) {
@@ -138,6 +138,37 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 				code[i] = c;
 			}
 			std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
+		} else if (p_.morton_sort >= 2) {
+			// k-d clusters: split the longest axis of the subset's bounding box at the median, rounded so
+			// that the left part holds a multiple of 256 (64 below 256) points, down to 64-point leaves.
+			// Every aligned run of 64 points (one wavefront's gathers) is then a compact box-shaped surface
+			// patch and every aligned 256 (one workgroup iteration) a subtree: fewer distinct DT cache lines
+			// per gather instruction than a space-filling curve gives (65 536-cube launch on the bunny:
+			// Morton 2.28 ms, Hilbert 2.13 ms, these clusters 1.94 ms; principal-axis splits 2.01 ms).
+			std::vector<std::pair<size_t, size_t>> stack{{0, N_}};
+			while (!stack.empty()) {
+				auto [lo, hi] = stack.back(); stack.pop_back();
+				const size_t n = hi - lo;
+				if (n <= 64) continue;
+				float bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+				for (size_t i = lo; i < hi; i++)
+					for (int k = 0; k < 3; k++) {
+						bmn[k] = std::min(bmn[k], source[3 * perm[i] + k]);
+						bmx[k] = std::max(bmx[k], source[3 * perm[i] + k]);
+					}
+				int ax = 0;
+				for (int k = 1; k < 3; k++) if (bmx[k] - bmn[k] > bmx[ax] - bmn[ax]) ax = k;
+				const size_t unit = n > 256 ? 256 : 64;
+				size_t nl = ((n / 2 + unit / 2) / unit) * unit;
+				if (nl == 0) nl = unit;
+				if (nl >= n) nl = n - (n % unit ? n % unit : unit);
+				std::nth_element(perm.begin() + lo, perm.begin() + lo + nl, perm.begin() + hi, [&](int32_t a, int32_t b) {
+					const float fa = source[3 * a + ax], fb = source[3 * b + ax];
+					return fa < fb || (fa == fb && a < b);                    // total order: the permutation is reproducible
+				});
+				stack.push_back({lo + nl, hi});
+				stack.push_back({lo, lo + nl});
+			}
 		}
 		src_perm_ = perm;
 		h_src_sorted_.resize(4 * N_);

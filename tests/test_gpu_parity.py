@@ -78,7 +78,7 @@ def _cubes(rng, n):
     return np.concatenate([c, w[:, None]], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize("layout,morton", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("layout,morton", [(1, 2), (0, 2), (1, 1), (1, 0)])
 def test_eval_bounds_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bunny_data10, rho10, layout, morton):
     """ub/lb of 3 rotations x 64 cubes x {no radius, level 3..7}: rel 1e-4 (summation order only;
     every per-point term is bit-identical)."""

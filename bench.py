@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--dt-layout", type=int, default=1)
     ap.add_argument("--dt-size", type=int, default=300, help="tuning only: the BASELINE workload is 300")
-    ap.add_argument("--morton", type=int, default=2, help="tuning only: source order 0 input / 1 Morton / 2 k-d clusters")
+    ap.add_argument("--morton", type=int, default=2, help="tuning only: source order 0 input / 1 Morton / 2 k-d order")
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
                     help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")

@@ -141,7 +141,7 @@ __device__ __forceinline__ unsigned axis_offset(const DtDesc& dt, int i)
 // ------------------------------------------------------------------------------------------------
 // grid: groups*chunks blocks of 256 threads.  A block owns kGroup consecutive cubes (the siblings
 // of one BnB expansion: same rotation, neighbouring translations -> neighbouring DT voxels) and a
-// contiguous chunk of the (Morton-sorted) source cloud; each point is loaded once (16 B) and
+// contiguous chunk of the (k-d-ordered) source cloud; each point is loaded once (16 B) and
 // reused for the 8 cubes.
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	// XCD-aware tiling (speed only): blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns
-	// the point chunks [x*cpx, (x+1)*cpx) -- a compact spatial patch of the Morton-sorted cloud -- and
+	// the point chunks [x*cpx, (x+1)*cpx) -- a compact spatial patch of the k-d-ordered cloud -- and
 	// walks the cube groups in order, so at any time one L2 serves gathers into the DT neighbourhood
 	// of ONE patch under nearby translations (a few MB) instead of the whole surface band.
 	int chunk, group;

@@ -115,7 +115,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		rot_coeff_[l] = 2 * std::sin(maxAngle / 2);
 	}
 
-	// ---- source cloud: (x,y,z,|p|), ordered for gather locality (morton_sort: 0 input order, 1 Morton curve, 2 k-d clusters) ----
+	// ---- source cloud: (x,y,z,|p|), ordered for gather locality (morton_sort: 0 input order, 1 Morton curve, 2 k-d order) ----
 	{
 		std::vector<int32_t> perm(N_);
 		for (size_t i = 0; i < N_; i++) perm[i] = (int32_t)i;
@@ -139,17 +139,19 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			}
 			std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return code[a] < code[b]; });
 		} else if (p_.morton_sort >= 2) {
-			// k-d clusters: split the longest axis of the subset's bounding box at the median, rounded so
-			// that the left part holds a multiple of 256 (64 below 256) points, down to 64-point leaves.
-			// Every aligned run of 64 points (one wavefront's gathers) is then a compact box-shaped surface
-			// patch and every aligned 256 (one workgroup iteration) a subtree: fewer distinct DT cache lines
-			// per gather instruction than a space-filling curve gives (65 536-cube launch on the bunny:
-			// Morton 2.28 ms, Hilbert 2.13 ms, these clusters 1.94 ms; principal-axis splits 2.01 ms).
+			// k-d order: split the longest axis of the subset's bounding box at the median, rounded so that
+			// the left part holds a multiple of 256 / 64 / 16 / 4 points (the largest that is smaller than the
+			// subset), down to single points.  Every aligned run of 64 points (one wavefront's gathers) is
+			// then a compact box-shaped surface patch, every aligned 4 and 16 lanes a sub-patch of it, and
+			// every aligned 256 (one workgroup iteration) a subtree: fewer distinct DT cache lines per gather
+			// instruction than a space-filling curve gives.  65 536-cube launch on the bunny: Morton 2.28 ms,
+			// Hilbert 2.13 ms, 64-point clusters 1.94 ms (principal-axis splits 2.01 ms), clusters ordered
+			// down to 4 points 1.85 ms, down to single points 1.84 ms.
 			std::vector<std::pair<size_t, size_t>> stack{{0, N_}};
 			while (!stack.empty()) {
 				auto [lo, hi] = stack.back(); stack.pop_back();
 				const size_t n = hi - lo;
-				if (n <= 64) continue;
+				if (n <= 1) continue;
 				float bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
 				for (size_t i = lo; i < hi; i++)
 					for (int k = 0; k < 3; k++) {
@@ -158,7 +160,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 					}
 				int ax = 0;
 				for (int k = 1; k < 3; k++) if (bmx[k] - bmn[k] > bmx[ax] - bmn[ax]) ax = k;
-				const size_t unit = n > 256 ? 256 : 64;
+				const size_t unit = n > 256 ? 256 : (n > 64 ? 64 : (n > 16 ? 16 : (n > 4 ? 4 : 1)));
 				size_t nl = ((n / 2 + unit / 2) / unit) * unit;
 				if (nl == 0) nl = unit;
 				if (nl >= n) nl = n - (n % unit ? n % unit : unit);

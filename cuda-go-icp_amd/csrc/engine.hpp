@@ -25,7 +25,7 @@ struct Params {
 	int rot_batch = 8;            // rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches)
 	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
 	int verbose = 0;
-	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d clusters of 64 (locality of the DT gathers)
+	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d order (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort): 1 yes, 0 host median splits, -1 auto (M > 262144)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -130,7 +130,7 @@ private:
 
 	hipStream_t stream_ = nullptr;
 	hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-	float4* d_src_ = nullptr;         // N  (x,y,z,|p|), Morton order
+	float4* d_src_ = nullptr;         // N  (x,y,z,|p|), k-d order (Params::morton_sort)
 	std::vector<int32_t> src_perm_;   // sorted position -> original index
 	std::vector<float> h_src_sorted_; // N*4
 	std::vector<float> h_target_;     // M*3 (kept for viz.ply)

@@ -95,7 +95,7 @@ typedef struct goicp_params {
 	int32_t wide_children;   /* 1: the rotation children's ub and lb inner searches run in lock-step; 0 = reference order */
 	int32_t icp_max_iter;    /* reference 10000 (src/goicp/jly_icp3d.hpp:114) */
 	int32_t verbose;
-	int32_t morton_sort;     /* source order on the device: 0 input order, 1 Morton curve, 2 k-d clusters of 64 points (default) */
+	int32_t morton_sort;     /* source order on the device: 0 input order, 1 Morton curve, 2 k-d order (default) */
 	int32_t rot_batch;       /* rotation nodes expanded per round when wide_children (default 8) */
 	int32_t kd_gpu_build;    /* k-d tree (box hierarchy) built on the device: 1 yes, 0 host, -1 auto (targets > 262144 points) */
 	float trim_fraction;     /* GoICP::trimFraction (src/goicp/jly_goicp.h:116): fraction of the largest residuals ignored; reference 0 */

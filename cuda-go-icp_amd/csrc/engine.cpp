@@ -779,6 +779,7 @@ void Engine::register_begin()
 {
 	cancel_.store(false);
 	early_exit_ = converged_ = false;
+	rot_ramp_ = 8;
 	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
 	cnt_ = Counters{};
 	while (!queue_.empty()) queue_.pop();
@@ -908,8 +909,12 @@ void Engine::process_parents(const std::vector<Node>& parents)
 StepStatus Engine::register_step(int max_rot_pops)
 {
 	int pops = 0;
-	const int P = p_.wide_children ? std::max(1, p_.rot_batch) : 1;
 	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
+		// Rotation parents expanded together: ramps 8, 16, 32 ... rot_batch.  Easy registrations end in
+		// the first rounds and pay for little speculation; long searches run with few, large launches
+		// (full bunny: 310 launches / 63 ms at a fixed 8, 52 launches / 55 ms at 64).
+		const int P = p_.wide_children ? std::max(1, std::min(p_.rot_batch, rot_ramp_)) : 1;
+		rot_ramp_ = std::min(rot_ramp_ * 2, 1 << 20);
 		std::vector<Node> parents;
 		while ((int)parents.size() < P && !queue_.empty() && pops < max_rot_pops) {
 			Node parent = queue_.top();

@@ -22,7 +22,7 @@ struct Params {
 	int device = -1;              // -1: current HIP device
 	int trans_batch = 32;         // translation nodes expanded per inner search per launch (1 = reference order)
 	int wide_children = 1;        // run the rotation children's inner searches concurrently (0 = reference order)
-	int rot_batch = 8;            // rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches)
+	int rot_batch = 64;           // most rotation nodes expanded per round when wide_children (their 8 children x {ub,lb} searches share launches); ramps up from 8
 	int icp_max_iter = 10000;     // jly_icp3d.hpp:114
 	int verbose = 0;
 	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d order (locality of the DT gathers)
@@ -164,6 +164,7 @@ private:
 	float opt_err_ = 1e10f;
 	float optR_[9], optT_[3], curR_[9], curT_[3];
 	bool early_exit_ = false, converged_ = false;
+	int rot_ramp_ = 8;
 	Counters cnt_;
 	std::atomic<bool> cancel_{false};
 	std::mutex mtx_;

@@ -34,12 +34,6 @@ __device__ __forceinline__ float wave_sum(float v)
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
 	return v;
 }
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
-}
 
 // XCD-aware bijective block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
 // each XCD a contiguous slice of the logical grid -> neighbouring cube groups (neighbouring DT

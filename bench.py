@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--dt-layout", type=int, default=1)
     ap.add_argument("--dt-size", type=int, default=300, help="tuning only: the BASELINE workload is 300")
+    ap.add_argument("--kd-gpu-build", type=int, default=-1, help="tuning only: target hierarchy built on the device 1 / host 0 / auto -1")
     ap.add_argument("--morton", type=int, default=2, help="tuning only: source order 0 input / 1 Morton / 2 k-d order")
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
@@ -144,7 +145,9 @@ def main():
         wname = "synthetic %s (SURVEY 8d)" % args.workload.upper()
     N, M, V = len(data), len(model), args.dt_size
 
-    reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, morton_sort=args.morton)
+    t_create = time.perf_counter()
+    reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, morton_sort=args.morton, kd_gpu_build=args.kd_gpu_build)
+    t_create = time.perf_counter() - t_create
     lib, h = reg._lib, reg.handle
     rots, recs, n_lb = make_batch(pkg, reg, args.expansions, 8, seed=1234 + rank)
     Bc = len(recs)
@@ -268,7 +271,7 @@ def main():
         # ---- end-to-end registration of the same clouds ----
         e2e = None
         if not args.no_e2e:
-            eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank)
+            eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, kd_gpu_build=args.kd_gpu_build)
             t1 = time.perf_counter()
             eng.run()
             wall = time.perf_counter() - t1
@@ -276,7 +279,7 @@ def main():
             e2e = {"register_s": round(wall, 4), "sse": float(r.best_sse), "cube_bounds": int(r.counters.cubes),
                    "cube_bounds_per_s": round(r.counters.cubes / wall, 1), "rot_pops": int(r.counters.rot_pops),
                    "trans_pops": int(r.counters.trans_pops), "icp_iters": int(r.counters.icp_iters),
-                   "dt_build_ms": round(r.dt_build_ms, 2)}
+                   "dt_build_ms": round(r.dt_build_ms, 2), "engine_create_s": round(t_create, 3)}
             if args.workload == "bunny":
                 e2e.update({"reference_cpu_register_s": 502.7, "reference_sse": 4.57226})
         cpu = None

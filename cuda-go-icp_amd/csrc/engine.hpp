@@ -5,6 +5,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <queue>
 #include <string>
@@ -27,7 +28,7 @@ struct Params {
 	int verbose = 0;
 	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d order (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
-	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort): 1 yes, 0 host median splits, -1 auto (M > 262144)
+	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 };
 
@@ -181,6 +182,8 @@ struct KdHost {
 	int K = 1, L = 64;
 };
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
+// fn(0..ntasks-1) on up to `threads` host threads (tasks claimed from a counter; the first exception is rethrown)
+void parallel_tasks(int threads, int ntasks, const std::function<void(int)>& fn);
 void rodrigues(float ax, float ay, float az, float R[9]);   // jly_goicp.cpp:449-467
 
 }  // namespace goicp

@@ -97,7 +97,7 @@ typedef struct goicp_params {
 	int32_t verbose;
 	int32_t morton_sort;     /* source order on the device: 0 input order, 1 Morton curve, 2 k-d order (default) */
 	int32_t rot_batch;       /* most rotation nodes expanded per round when wide_children (default 64; rounds ramp 8, 16, 32 ...) */
-	int32_t kd_gpu_build;    /* k-d tree (box hierarchy) built on the device: 1 yes, 0 host, -1 auto (targets > 262144 points) */
+	int32_t kd_gpu_build;    /* k-d tree (box hierarchy) built on the device (Morton order, looser boxes): 1 yes, 0 or -1 host median splits (default) */
 	float trim_fraction;     /* GoICP::trimFraction (src/goicp/jly_goicp.h:116): fraction of the largest residuals ignored; reference 0 */
 } goicp_params;
 

@@ -177,7 +177,7 @@ private:
 
 // ---- host utilities (config_io.cpp, kdtree.cpp) ----
 struct KdHost {
-	std::vector<std::vector<float>> boxes;   // per level: 64^l groups x 384 floats
+	std::vector<std::vector<float>> boxes;   // per level: groups x 384 floats (level 0: the root; level l: F*64^(l-1) groups, F = real children of the root)
 	std::vector<float4> pts;                 // kLeafSlots slots per leaf
 	int K = 1, L = 64;
 };

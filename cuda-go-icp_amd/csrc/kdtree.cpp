@@ -38,15 +38,21 @@ void parallel_tasks(int threads, int ntasks, const std::function<void(int)>& fn)
 	if (err) std::rethrow_exception(err);
 }
 
-// Balanced binary k-d tree by median splits along the widest extent (depth 6K, 64^K leaves of
-// <= kLeafSlots points), flattened into K levels of 64-ary box groups: a level-l group is the
-// subtree rooted at binary depth 6l, its 64 children are the nodes 6 binary levels below.
+// Balanced binary k-d tree by median splits along the widest extent, of the smallest depth D whose
+// 2^D leaves hold <= leaf_max points each, flattened into K = ceil(D/6) levels of 64-ary box groups.
+// The ROOT group is the sparse one: it has F = 2^(D - 6(K-1)) real children (the binary nodes at that
+// depth; the other child slots are empty boxes, which no query ever enters), every group below has
+// 64.  A level-l group (l >= 1) is the binary node at depth d_l = log2(F) + 6(l-1) with index g, its
+// children are the nodes 6 binary levels below (g*64 + c): the walker's node arithmetic needs no
+// child pointers and no per-level fan-out.  Sizing the depth to the cloud keeps leaves full (100 k
+// points: 8 192 leaves of 12 instead of 262 144 leaves of 0.4; 1 M: 65 536 of 15 instead of 262 144 of 4).
 void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 {
-	int K = 1;
-	while (K < kMaxLevels && (long long)leaf_max * (1LL << (6 * K)) < (long long)M) K++;
-	if ((long long)leaf_max * (1LL << (6 * K)) < (long long)M) throw std::invalid_argument("goicp: target cloud too large for the k-d tree");
-	const int D = 6 * K, L = 1 << D;
+	int D = 0;
+	while (D < 6 * kMaxLevels && ((long long)leaf_max << D) < (long long)M) D++;
+	if (((long long)leaf_max << D) < (long long)M) throw std::invalid_argument("goicp: target cloud too large for the k-d tree");
+	const int K = std::max(1, (D + 5) / 6), L = 1 << D;
+	const int d1 = D - 6 * (K - 1);              // binary depth of the root group's children; F = 2^d1
 	out->K = K; out->L = L;
 	std::vector<int> idx(M);
 	std::iota(idx.begin(), idx.end(), 0);
@@ -78,11 +84,12 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 	// index ranges and heap slots; the result does not depend on the schedule): 1 M points in ~0.1 s
 	// instead of 0.35 s
 	constexpr int kTop = 16;
-	for (int n = 1; n < kTop; n++) split_node(n);
-	parallel_tasks(M >= (1 << 16) ? kTop : 1, kTop, [&](int t) {
-		for (int d = 0; ((kTop + t) << d) < L; d++)
-			for (int n = (kTop + t) << d; n < (kTop + t + 1) << d; n++) split_node(n);
-	});
+	for (int n = 1; n < std::min(kTop, L); n++) split_node(n);
+	if (L > kTop)
+		parallel_tasks(M >= (1 << 16) ? kTop : 1, kTop, [&](int t) {
+			for (int d = 0; ((kTop + t) << d) < L; d++)
+				for (int n = (kTop + t) << d; n < ((kTop + t + 1) << d); n++) split_node(n);
+		});
 	// leaves: node L + f, left to right
 	float pad_w;
 	const int pad_id = INT32_MAX;
@@ -109,14 +116,17 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 			box[n].lo[k] = std::min(box[2 * (size_t)n].lo[k], box[2 * (size_t)n + 1].lo[k]);
 			box[n].hi[k] = std::max(box[2 * (size_t)n].hi[k], box[2 * (size_t)n + 1].hi[k]);
 		}
-	// level l: groups = binary nodes at depth 6l (heap index 2^(6l) + g), children = nodes at depth 6(l+1)
+	// level 0: the root group, children = the F nodes at depth d1; level l >= 1: the 2^(d1 + 6(l-1))
+	// nodes at that depth, children = the nodes 6 levels below
+	const Box empty{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
 	out->boxes.assign(K, std::vector<float>());
 	for (int l = 0; l < K; l++) {
-		const size_t groups = (size_t)1 << (6 * l);
+		const int dg = l == 0 ? 0 : d1 + 6 * (l - 1), dc = l == 0 ? d1 : dg + 6;   // depth of the groups / of their children
+		const size_t groups = (size_t)1 << dg, fan = (size_t)1 << (dc - dg);
 		out->boxes[l].assign(groups * 384, 0.f);
 		for (size_t g = 0; g < groups; g++)
-			for (int c = 0; c < 64; c++) {
-				const Box& bx = box[((size_t)1 << (6 * (l + 1))) + g * 64 + c];
+			for (size_t c = 0; c < 64; c++) {
+				const Box& bx = c < fan ? box[((size_t)1 << dc) + g * fan + c] : empty;
 				float* rec = &out->boxes[l][g * 384];
 				for (int k = 0; k < 3; k++) { rec[64 * k + c] = bx.lo[k]; rec[192 + 64 * k + c] = bx.hi[k]; }
 			}

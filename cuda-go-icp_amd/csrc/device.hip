@@ -130,6 +130,29 @@ __device__ __forceinline__ unsigned axis_offset(const DtDesc& dt, int i)
 	return (__umul24(hi, (unsigned)(dt.VB * dt.VB)) << 6) | (lo << 4);
 }
 
+// the 8 cube records of workgroup `group`: read from the batch, or derived from one expansion record with
+// the search driver's own float operations (engine.cpp / jly_goicp.cpp:262-273: w' = w/2, corner +
+// bit*w', centre = corner + w'/2, delta = float(sqrt3/2 * double(w')))
+__device__ __forceinline__ void load_group(const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int group, int B,
+                                           CubeRec cr[kGroup])
+{
+	if (parents) {
+		const ParentRec pr = parents[group];
+		const float w = pr.w / 2;
+		const float delta = (float)(1.732050808 / 2.0 * (double)w);
+#pragma unroll
+		for (int c = 0; c < kGroup; c++) {
+			const float cx = pr.x + (float)(c & 1) * w, cy = pr.y + (float)((c >> 1) & 1) * w, cz = pr.z + (float)((c >> 2) & 1) * w;
+			cr[c].tx = cx + w / 2; cr[c].ty = cy + w / 2; cr[c].tz = cz + w / 2;
+			cr[c].delta = delta; cr[c].coeff = pr.coeff; cr[c].rot = pr.rot;
+		}
+	} else {
+		const int c0 = group * kGroup;
+#pragma unroll
+		for (int c = 0; c < kGroup; c++) cr[c] = cubes[c0 + c < B ? c0 + c : B - 1];
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // (a) cube bounds
 // ------------------------------------------------------------------------------------------------
@@ -140,7 +163,7 @@ __device__ __forceinline__ unsigned axis_offset(const DtDesc& dt, int i)
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
-    const CubeRec* __restrict__ cubes, int B, int groups, int chunks, int chunk_pts,
+    const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
     float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	// XCD-aware tiling (speed only): blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns
@@ -159,13 +182,10 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 	const int c0 = group * kGroup;
 
 	CubeRec cr[kGroup];
+	load_group(cubes, parents, group, B, cr);
 	bool uniform = true;
 #pragma unroll
-	for (int c = 0; c < kGroup; c++) {
-		int ci = c0 + c < B ? c0 + c : B - 1;
-		cr[c] = cubes[ci];
-		uniform = uniform && (cr[c].rot == cr[0].rot);
-	}
+	for (int c = 0; c < kGroup; c++) uniform = uniform && (cr[c].rot == cr[0].rot);
 	const Rot9 R0 = rots[cr[0].rot];
 	// The 8 children of one BnB expansion share, per axis, only TWO translation values
 	// (jly_goicp.cpp:267-273: corner + (j>>a & 1)*w + w/2), one rotation, one delta, one coeff.
@@ -296,15 +316,15 @@ __global__ void bounds_finalize(const float* __restrict__ scratch, int B, int gr
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
-    const CubeRec* __restrict__ cubes, int B, int inliers, float* __restrict__ ub_out, float* __restrict__ lb_out)
+    const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int inliers,
+    float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	__shared__ unsigned hist[kGroup][2048];
 	__shared__ unsigned sel_prefix[kGroup], sel_rem[kGroup];
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
 	const int c0 = blockIdx.x * kGroup;
 	CubeRec cr[kGroup];
-#pragma unroll
-	for (int c = 0; c < kGroup; c++) cr[c] = cubes[c0 + c < B ? c0 + c : B - 1];
+	load_group(cubes, parents, blockIdx.x, B, cr);
 	if (threadIdx.x < kGroup) { sel_prefix[threadIdx.x] = 0u; sel_rem[threadIdx.x] = (unsigned)inliers; }
 
 	auto residual = [&](const float4& p, int c) -> float {
@@ -391,18 +411,22 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
 		const float T = __uint_as_float(sel_prefix[c]);
 		const float n_eq = (float)sel_rem[c];
 		if (threadIdx.x < kGroup) s += n_eq * (T * T);
-		else { const float dis = fmaxf(T - cubes[c0 + c < B ? c0 + c : B - 1].delta, 0.f); s += n_eq * (dis * dis); }
+		else {
+			const float delta_c = parents ? cr[0].delta : cubes[c0 + c < B ? c0 + c : B - 1].delta;   // read, not cr[c]: no dynamic register indexing
+			const float dis = fmaxf(T - delta_c, 0.f);
+			s += n_eq * (dis * dis);
+		}
 		if (c0 + c < B) (threadIdx.x < kGroup ? ub_out : lb_out)[c0 + c] = s;
 	}
 }
 
-hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, int B,
+hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents, int B,
                               int inliers, float* ub, float* lb, hipStream_t stream)
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
 	const dim3 grid((B + kGroup - 1) / kGroup), block(kBoundsThreads);
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, B, inliers, ub, lb);
-	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, B, inliers, ub, lb);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
+	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
 	return hipGetLastError();
 }
 
@@ -433,7 +457,7 @@ size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out)
 	return (size_t)g * c * 2 * kGroup;
 }
 
-hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes,
+hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream)
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
@@ -441,9 +465,9 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 	bounds_shape(B, N, &groups, &chunks, &chunk_pts);
 	dim3 grid(groups * chunks), block(kBoundsThreads);
 	if (dt.layout == 0)
-		hipLaunchKernelGGL(bounds_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, B, groups, chunks, chunk_pts, scratch, ub, lb);
+		hipLaunchKernelGGL(bounds_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
 	else
-		hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, B, groups, chunks, chunk_pts, scratch, ub, lb);
+		hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
 	if (chunks > 1) {
 		int t = groups * 2 * kGroup;
 		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, B, groups, chunks, ub, lb);

@@ -34,6 +34,16 @@ struct CubeRec {
 };
 static_assert(sizeof(CubeRec) == 24, "CubeRec layout");
 
+// One BnB expansion: the kernels derive the 8 children themselves (same float operations as the host,
+// jly_goicp.cpp:262-273), so the search driver uploads 24 B per expansion instead of 192.
+struct ParentRec {
+	float x, y, z;      // parent cube corner
+	float w;            // parent cube width
+	float coeff;        // rotation uncertainty coefficient of the children, 0 for the ub pass
+	int32_t rot;        // index into the rotation table
+};
+static_assert(sizeof(ParentRec) == 24, "ParentRec layout");
+
 struct Rot9 { float r[9]; };   // row-major
 
 // Flattened k-d tree over the target cloud.  The host builds a balanced binary k-d
@@ -61,11 +71,12 @@ constexpr int kIcpAcc = 16;        // sum(q-cq)[3] sum(m-cm)[3] sum((q-cq)(m-cm)
 // ---- bounds ---------------------------------------------------------------------------------
 // scratch must hold groups*chunks*2*kGroup floats.  ub/lb: [B].
 size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out);
-hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes,
+// `parents` != nullptr: B/8 expansions, `cubes` ignored
+hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream);
 
 // trimmed form: only the `inliers` smallest residuals of each cube are summed (jly_goicp.cpp:293-315)
-hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, int B,
+hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents, int B,
                               int inliers, float* ub, float* lb, hipStream_t stream);
 
 // ---- ICP ------------------------------------------------------------------------------------

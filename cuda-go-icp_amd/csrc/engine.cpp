@@ -339,8 +339,8 @@ void Engine::release()
 	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_);
 	hipFree(d_nn_d2_); hipFree(d_nn_slot_); hipFree(d_include_);
 	for (Stage& st : stage_) {
-		hipFree(st.d_cubes); hipFree(st.d_ub); hipFree(st.d_lb);
-		hipHostFree(st.h_cubes); hipHostFree(st.h_ub); hipHostFree(st.h_lb);
+		hipFree(st.d_parents); hipFree(st.d_ub);
+		hipHostFree(st.h_parents); hipHostFree(st.h_ub);
 		if (st.ev) hipEventDestroy(st.ev);
 		st = Stage{};
 	}
@@ -394,7 +394,7 @@ void Engine::ensure_batch(size_t B, size_t K)
 // ------------------------------------------------------------------------------------------------
 // operators
 // ------------------------------------------------------------------------------------------------
-void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s)
+void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s, const ParentRec* d_parents)
 {
 	size_t need = bounds_scratch_floats(B, (int)N_, nullptr, nullptr);
 	if (need > cap_scratch_) {
@@ -404,9 +404,9 @@ void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, 
 		cap_scratch_ = need;
 	}
 	if (inliers_ < (int)N_)
-		HIPCHK(launch_bounds_trim(d_src_, (int)N_, dt_, d_rots, d_cubes, B, inliers_, d_ub, d_lb, s ? s : stream_));
+		HIPCHK(launch_bounds_trim(d_src_, (int)N_, dt_, d_rots, d_cubes, d_parents, B, inliers_, d_ub, d_lb, s ? s : stream_));
 	else
-		HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
+		HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, d_parents, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
 	cnt_.bounds_launches++;
 }
 
@@ -622,14 +622,13 @@ void Engine::ensure_stage(int k, size_t B)
 	if (!st.ev) HIPCHK(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
 	if (B <= st.cap) return;
 	const size_t cap = std::max<size_t>(B, st.cap * 2);
-	hipFree(st.d_cubes); hipFree(st.d_ub); hipFree(st.d_lb);
-	hipHostFree(st.h_cubes); hipHostFree(st.h_ub); hipHostFree(st.h_lb);
-	HIPCHK(hipMalloc(&st.d_cubes, sizeof(CubeRec) * cap));
-	HIPCHK(hipMalloc(&st.d_ub, sizeof(float) * cap));
-	HIPCHK(hipMalloc(&st.d_lb, sizeof(float) * cap));
-	HIPCHK(hipHostMalloc(&st.h_cubes, sizeof(CubeRec) * cap));
-	HIPCHK(hipHostMalloc(&st.h_ub, sizeof(float) * cap));
-	HIPCHK(hipHostMalloc(&st.h_lb, sizeof(float) * cap));
+	hipFree(st.d_parents); hipFree(st.d_ub);
+	hipHostFree(st.h_parents); hipHostFree(st.h_ub);
+	st.d_parents = nullptr; st.d_ub = nullptr; st.h_parents = nullptr; st.h_ub = nullptr; st.cap = 0;
+	HIPCHK(hipMalloc(&st.d_parents, sizeof(ParentRec) * (cap / 8 + 1)));
+	HIPCHK(hipMalloc(&st.d_ub, sizeof(float) * 2 * cap));                 // ub[B] | lb[B]: one copy back per round
+	HIPCHK(hipHostMalloc(&st.h_parents, sizeof(ParentRec) * (cap / 8 + 1)));
+	HIPCHK(hipHostMalloc(&st.h_ub, sizeof(float) * 2 * cap));
 	st.cap = cap;
 }
 
@@ -678,20 +677,14 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 		size_t o = 0;
 		for (auto* s : grp[k])
 			for (const Node& par : s->parents) {
-				const float w = par.w / 2;                                  // :262
-				const float delta = (float)(kSQRT3 / 2.0 * (double)w);     // :263
-				for (int j = 0; j < 8; j++) {
-					float cx = par.x + (j & 1) * w, cy = par.y + (j >> 1 & 1) * w, cz = par.z + (j >> 2 & 1) * w;
-					CubeRec& c = st.h_cubes[o++];
-					c.tx = cx + w / 2; c.ty = cy + w / 2; c.tz = cz + w / 2;   // :271-273
-					c.delta = delta; c.coeff = s->coeff; c.rot = s->rot_slot;
-				}
+				// the kernels expand the 8 children themselves (load_group in device.hip; jly_goicp.cpp:262-273)
+				ParentRec& r = st.h_parents[o++];
+				r.x = par.x; r.y = par.y; r.z = par.z; r.w = par.w; r.coeff = s->coeff; r.rot = s->rot_slot;
 			}
 		st.B = B;
-		HIPCHK(hipMemcpyAsync(st.d_cubes, st.h_cubes, sizeof(CubeRec) * B, hipMemcpyHostToDevice, stream_));
-		eval_bounds_dev(d_rots_, st.d_cubes, (int)B, st.d_ub, st.d_lb, stream_);
-		HIPCHK(hipMemcpyAsync(st.h_ub, st.d_ub, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
-		HIPCHK(hipMemcpyAsync(st.h_lb, st.d_lb, sizeof(float) * B, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(st.d_parents, st.h_parents, sizeof(ParentRec) * (B / 8), hipMemcpyHostToDevice, stream_));
+		eval_bounds_dev(d_rots_, nullptr, (int)B, st.d_ub, st.d_ub + B, stream_, st.d_parents);
+		HIPCHK(hipMemcpyAsync(st.h_ub, st.d_ub, sizeof(float) * 2 * B, hipMemcpyDeviceToHost, stream_));
 		HIPCHK(hipEventRecord(st.ev, stream_));
 		return true;
 	};
@@ -705,7 +698,7 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 				c.w = par.w / 2;
 				for (int j = 0; j < 8; j++, o++) {
 					c.x = par.x + (j & 1) * c.w; c.y = par.y + (j >> 1 & 1) * c.w; c.z = par.z + (j >> 2 & 1) * c.w;
-					const float ub = st.h_ub[o], lb = st.h_lb[o];
+					const float ub = st.h_ub[o], lb = st.h_ub[st.B + o];
 					s->cubes++;
 					if (ub < s->best) { s->best = ub; s->best_node = c; s->improved = true; }   // :319-324
 					if (lb >= s->best) continue;                                                  // :327

@@ -76,7 +76,7 @@ public:
 	// path's semantics: cubes = B x {centre xyz, child width}; level < 0 => no rotation radius.
 	void eval_bounds(const float R[9], const float* cubes4, size_t B, int level, float* ub, float* lb);
 	void eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cubes, size_t B, float* ub, float* lb);
-	void eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s);
+	void eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s, const ParentRec* d_parents = nullptr);
 	float time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters);
 	float eval_sse(const float R[9], const float t[3]);
 	float inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c);
@@ -149,8 +149,8 @@ private:
 	float* d_ub_ = nullptr; float* d_lb_ = nullptr; float* h_ub_ = nullptr; float* h_lb_ = nullptr;
 	float* d_scratch_ = nullptr;
 	struct Stage {   // per-group staging of the pipelined inner-BnB rounds
-		CubeRec* d_cubes = nullptr; CubeRec* h_cubes = nullptr;
-		float* d_ub = nullptr; float* d_lb = nullptr; float* h_ub = nullptr; float* h_lb = nullptr;
+		ParentRec* d_parents = nullptr; ParentRec* h_parents = nullptr;   // one record per expansion; the kernels derive the 8 children
+		float* d_ub = nullptr; float* h_ub = nullptr;   // ub[B] followed by lb[B]
 		size_t cap = 0, B = 0; hipEvent_t ev = nullptr;
 	} stage_[2];
 	// icp staging

@@ -238,6 +238,20 @@ def test_nn_ties_on_a_lattice(pkg, oracle_mod, side):
     reg.close()
 
 
+@pytest.mark.parametrize("M", [17, 33, 1024, 1025, 2049, 65536, 65537])
+def test_nn_hierarchy_shapes(pkg, oracle_mod, M):
+    """The hierarchy's binary depth follows the cloud (full leaves, sparse root group): depths 1, 2, 6, 7, 8,
+    12, 13 = one, two and three box levels with 2 .. 64 real root children.  Exact vs brute force."""
+    rng = np.random.default_rng(M)
+    target = rng.uniform(-0.6, 0.6, (M, 3)).astype(np.float32)
+    reg = pkg.Registration(target, target[:8].copy(), 1e-3, dt_size=48)
+    q = np.concatenate([rng.uniform(-0.8, 0.8, (600, 3)), target[rng.integers(0, M, 200)]]).astype(np.float32)
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    reg.close()
+
+
 def test_nn_three_level_hierarchy(pkg, oracle_mod):
     """M = 120 000 > 64*64*16 exercises the K = 3 box hierarchy (BASELINE configs[2]/[4] sizes): exact vs
     brute force, including queries far outside the cloud and outside the DT grid."""

@@ -15,12 +15,15 @@ N = 30 379 source; committed data fixtures, tests/golden/*.f32), distance transf
   value  = cube bounds evaluated by all ranks / wall time of the K timed steps (max over ranks).
 Also reported: ICP iterations/s (NN + sums + SVD update, host round trip included), an end-to-end
 registration of the same clouds (exact cube-bound count / wall time), the roofline of the dominant
-kernel (HIP events on the launch stream) and the CPU oracle timed on the host cores.
+kernel (HIP events on the launch stream) and the CPU baseline timed on the host cores: the reference's own
+InnerBnB (oracle/_ref/ref_harness, compiled from the reference's sources in the build container) when that
+binary travelled with the snapshot, and the oracle port (1 thread and all cores) either way.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -84,6 +87,23 @@ def cpu_baseline(reg, model, data, seconds=6.0):
     _, _, _, it = kd.icp_run(data, np.eye(3), np.zeros(3), 8, -1e30)
     out["icp_iters_per_s_1thread"] = it / (time.perf_counter() - t0)
     return out
+
+
+def reference_baseline(seconds=10.0):
+    """oracle/_ref/ref_harness (the REAL reference CPU Go-ICP, compiled from its sources by oracle/Makefile in the
+    build container; it travels with the snapshot): the reference's own InnerBnB on the fixture clouds, timed
+    on this host.  None when the binary is not there."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    g = os.path.join(ROOT, "tests", "golden")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "bench", os.path.join(g, "model_bunny.f32"), os.path.join(g, "data_bunny.f32"), str(seconds)],
+                           capture_output=True, text=True, timeout=240)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                      # a baseline leg must never take the GPU measurement down
+        print("reference baseline unavailable: %r" % (e,), file=sys.stderr)
+        return None
 
 
 def main():
@@ -285,10 +305,19 @@ def main():
         cpu = None
         if not args.no_cpu:
             c = cpu_baseline(reg, model, data)
-            cpu = {"value": round(c["1thread"], 1), "unit": "cube-bounds/s", "cores": 1, "kind": "port",
-                   "sample": "oracle cube_bound (restated InnerBnB body) on the same DT/cloud, ~6 s per leg, alternating ub/lb batches of 64 cubes; all-core leg = OpenMP over cubes",
-                   "allcores_value": round(c["allcores"], 1), "allcores": c["ncores"],
-                   "icp_iters_per_s_1thread": round(c["icp_iters_per_s_1thread"], 2)}
+            port = {"port_value": round(c["1thread"], 1), "port_allcores_value": round(c["allcores"], 1), "port_allcores": c["ncores"],
+                    "port_sample": "oracle cube_bound (restated InnerBnB body) on the same DT/cloud, ~6 s per leg, alternating ub/lb batches of 64 cubes; all-core leg = OpenMP over cubes",
+                    "icp_iters_per_s_1thread": round(c["icp_iters_per_s_1thread"], 2)}
+            ref = reference_baseline() if args.workload == "bunny" else None
+            if ref:
+                cpu = {"value": ref["cube_bounds_per_s"], "unit": "cube-bounds/s", "cores": 1, "kind": "reference",
+                       "sample": "oracle/_ref/ref_harness bench: the reference's own GoICP::InnerBnB (jly_goicp.cpp, -O2) on the same clouds, "
+                                 "%d alternating ub/lb searches over seeded rotations in %.1f s = %d translation nodes x 8 children; "
+                                 "its DT build (%.1f s) is outside the timed region" % (ref["inner_bnb_calls"], ref["seconds"], ref["trans_pops"], ref["dt_build_s"]),
+                       "reference_dt_build_s": ref["dt_build_s"]}
+            else:
+                cpu = {"value": port["port_value"], "unit": "cube-bounds/s", "cores": 1, "kind": "port", "sample": port["port_sample"]}
+            cpu.update(port)
         out = {"metric": "bnb_cube_bounds_per_s", "value": round(value, 1), "unit": "cube-bounds/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",

@@ -16,6 +16,7 @@
 //   units  <outdir> <model.txt> <data.txt> <stride>
 //   cloud  <out.f32> <cloud.txt>
 //   trim   <outdir> <model.txt> <data.txt> <stride> <trim_fraction>
+//   bench  <model.f32> <data.f32> <seconds>      (bench.py's cpu_baseline leg: the reference's own InnerBnB, timed)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -467,6 +468,76 @@ static int cmd_cloud(int argc, char** argv)
 	return 0;
 }
 
+
+// ---------------------------------------------------------------- bench
+// The reference's own GoICP::InnerBnB on the committed fixture clouds (raw little-endian float32 xyz),
+// timed for about <seconds> of wall clock after the DT build: alternating upper-bound (no rotation
+// uncertainty) and lower-bound searches from the standard translation root, over seeded rotations,
+// with a realistic incumbent.  Every popped translation node evaluates its 8 children
+// (jly_goicp.cpp:262-315), so cube bounds = 8 x the reference's own tNodeCount.
+static std::vector<glm::vec3> load_f32(const char* path)
+{
+	FILE* f = fopen(path, "rb");
+	if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+	fseek(f, 0, SEEK_END);
+	const long bytes = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	std::vector<glm::vec3> out((size_t)bytes / 12);
+	if (fread(out.data(), 12, out.size(), f) != out.size()) exit(2);
+	fclose(f);
+	return out;
+}
+
+static int cmd_bench(int argc, char** argv)
+{
+	if (argc < 5) return 1;
+	auto model = load_f32(argv[2]);
+	auto data = load_f32(argv[3]);
+	const double budget = atof(argv[4]);
+	mse_threshold = 1e-3f;
+	GoICP g(mse_threshold);
+	g.pModel = model.data(); g.Nm = (int)model.size();
+	g.pData = data.data();   g.Nd = (int)data.size();
+	const double t_dt = now_s();
+	g.BuildDT();
+	const double dt_build_s = now_s() - t_dt;
+	g.Initialize();
+	const int N = g.Nd;
+	const TRANSNODE rootT = g.initNodeTrans;
+	const float incumbent = 35.0f * (float)N / 3038.0f;          // as the "full" golden cases
+	std::mt19937 rng(20241223u);
+	std::uniform_real_distribution<float> ua(-3.14159265f, 3.14159265f);
+	long long calls = 0;
+	const long long pops0 = tNodeCount;
+	const double t0 = now_s();
+	while (now_s() - t0 < budget) {
+		float v[3];
+		do { v[0] = ua(rng); v[1] = ua(rng); v[2] = ua(rng); } while (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > 9.8696f);
+		float R[9];
+		rodrigues(v, R);
+		for (int i = 0; i < N; i++) {            // jly_goicp.cpp:470-476
+			POINT3D& p = g.pData[i];
+			g.pDataTemp[i].x = R[0] * p.x + R[1] * p.y + R[2] * p.z;
+			g.pDataTemp[i].y = R[3] * p.x + R[4] * p.y + R[5] * p.z;
+			g.pDataTemp[i].z = R[6] * p.x + R[7] * p.y + R[8] * p.z;
+		}
+		const int level = 3 + (int)(calls / 2 % 5);
+		for (int pass = 0; pass < 2 && now_s() - t0 < budget; pass++) {
+			g.initNodeTrans = rootT;
+			g.optError = incumbent;
+			TRANSNODE best; best.x = best.y = best.z = best.w = 0;
+			g.InnerBnB(pass ? g.maxRotDis[level] : NULL, &best);
+			calls++;
+		}
+	}
+	const double sec = now_s() - t0;
+	const long long pops = tNodeCount - pops0;
+	printf("{\"kind\": \"reference\", \"Nd\": %d, \"Nm\": %d, \"dt_build_s\": %.3f, \"seconds\": %.3f, \"inner_bnb_calls\": %lld, "
+	       "\"trans_pops\": %lld, \"cube_bounds\": %lld, \"cube_bounds_per_s\": %.1f}\n",
+	       N, g.Nm, dt_build_s, sec, calls, pops, 8 * pops, 8.0 * (double)pops / sec);
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	if (argc < 3) { fprintf(stderr, "usage: ref_harness e2e|units <outdir> ...\n"); return 1; }
@@ -474,5 +545,6 @@ int main(int argc, char** argv)
 	if (!strcmp(argv[1], "units")) return cmd_units(argc, argv);
 	if (!strcmp(argv[1], "cloud")) return cmd_cloud(argc, argv);
 	if (!strcmp(argv[1], "trim")) return cmd_trim(argc, argv);
+	if (!strcmp(argv[1], "bench")) return cmd_bench(argc, argv);
 	return 1;
 }

@@ -230,6 +230,33 @@ def main():
         except Exception as e:      # reported, never fatal for the headline line
             sharded_res = {"error": repr(e)}
 
+    # ---- ICP iterations/s: the loop does not shard, so N GPUs run N replicas side by side ----
+    icp = None
+    if not args.no_icp:
+        ms = C.c_float()
+        Ri, ti = np.eye(3, dtype=np.float32).reshape(9).copy(), np.zeros(3, np.float32)
+        err, it = C.c_float(), C.c_int32()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 5, -1e30, C.byref(err), C.byref(it)))
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 200, -1e30, C.byref(err), C.byref(it)))
+        rate = torch.tensor([it.value / (time.perf_counter() - t1)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(rate, op=dist.ReduceOp.SUM)
+        icp_rate = float(rate.item())
+        B.check(lib.goicp_time_icp_pass(h, fp(Ri), fp(ti), 50, C.byref(ms)))
+        D = int(np.ceil(np.log2(M / 16.0)))
+        icp_bytes = N * (16.0 + 4.0 + D * 24.0 + 16 * 16.0)       # query + DT seed + root-to-leaf box records (24 B) + one leaf of 16 float4 slots
+        nn_gbs = icp_bytes / (ms.value * 1e-3) / 1e9
+        icp = {"icp_iters_per_s": round(icp_rate, 1), "icp_replicas": world, "icp_pass_kernel_ms": round(ms.value, 4),
+               "icp_pass_algorithmic_GBs": round(nn_gbs, 1), "icp_bytes_per_iter": icp_bytes,
+               "roofline_nn": {"bound": "hbm", "kernel": "goicp::icp_pass_kernel + icp_finalize_update", "achieved": round(nn_gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "limiter": "latency: the dependent seed -> group -> leaf loads of the slowest wavefront (DESIGN 3.2)"},
+               "pose": "ICP-only local minimum reached from identity (205 forced iterations)"}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the launch stream, live ----
@@ -250,6 +277,9 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
+        if traffic is not None:     # the committed counters belong to exactly this workload
+            roofline["limiter"] = ("cloud and DT are cache-resident at this size: the texture-address units are 100 % busy "
+                                   "(TA_TA_BUSY_sum in profiles/r01_e_pmc_bounds.json), 27.9 cycles per 64-lane gather instruction against a floor of 16")
         # ---- what this GPU's HBM actually streams (device-to-device copy of 2 GiB, read + write counted) ----
         a_ = torch.empty(1 << 29, dtype=torch.float32, device=dev); b_ = torch.empty_like(a_)
         b_.copy_(a_); torch.cuda.synchronize()
@@ -272,22 +302,6 @@ def main():
         roofline["host_pointer_call_ms"] = round(host_ms, 4)
         roofline["host_pointer_cube_bounds_per_s"] = round(Bc / (host_ms * 1e-3), 1)
         assert np.array_equal(h_ub, d_ub.cpu().numpy()), "host-pointer and device-pointer entry points disagree"
-        # ---- ICP iterations/s ----
-        icp = None
-        if not args.no_icp:
-            Ri, ti = np.eye(3, dtype=np.float32).reshape(9).copy(), np.zeros(3, np.float32)
-            err, it = C.c_float(), C.c_int32()
-            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-            B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 5, -1e30, C.byref(err), C.byref(it)))
-            t1 = time.perf_counter()
-            B.check(lib.goicp_icp_run(h, fp(Ri), fp(ti), 200, -1e30, C.byref(err), C.byref(it)))
-            icp_rate = it.value / (time.perf_counter() - t1)
-            B.check(lib.goicp_time_icp_pass(h, fp(Ri), fp(ti), 50, C.byref(ms)))
-            D = int(np.ceil(np.log2(M / 16.0)))
-            icp_bytes = N * (16.0 + 4.0 + D * 24.0 + 16 * 16.0)       # query + DT seed + root-to-leaf box records (24 B) + one leaf of 16 float4 slots
-            icp = {"icp_iters_per_s": round(icp_rate, 1), "icp_pass_kernel_ms": round(ms.value, 4),
-                   "icp_pass_algorithmic_GBs": round(icp_bytes / (ms.value * 1e-3) / 1e9, 1), "icp_bytes_per_iter": icp_bytes,
-                   "pose": "ICP-only local minimum reached from identity (205 forced iterations)"}
         # ---- end-to-end registration of the same clouds ----
         e2e = None
         if not args.no_e2e:
@@ -303,7 +317,7 @@ def main():
             if args.workload == "bunny":
                 e2e.update({"reference_cpu_register_s": 502.7, "reference_sse": 4.57226})
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             c = cpu_baseline(reg, model, data)
             port = {"port_value": round(c["1thread"], 1), "port_allcores_value": round(c["allcores"], 1), "port_allcores": c["ncores"],
                     "port_sample": "oracle cube_bound (restated InnerBnB body) on the same DT/cloud, ~6 s per leg, alternating ub/lb batches of 64 cubes; all-core leg = OpenMP over cubes",

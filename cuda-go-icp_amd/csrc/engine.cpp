@@ -91,6 +91,11 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	if (!(p_.mse_threshold > 0.f)) p_.mse_threshold = 1e-10f;             // the reference clamps the same way (src/common.cpp:64)
 	for (size_t i = 0; i < 3 * M; i++) if (!std::isfinite(target[i])) throw std::invalid_argument("goicp: non-finite coordinate in the target cloud");
 	for (size_t i = 0; i < 3 * N; i++) if (!std::isfinite(source[i])) throw std::invalid_argument("goicp: non-finite coordinate in the source cloud");
+	double t_mark = now_ms();
+	auto lap = [&](const char* what) {
+		if (p_.verbose) std::fprintf(stderr, "[goicp] create: %-28s %8.2f ms\n", what, now_ms() - t_mark);
+		t_mark = now_ms();
+	};
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		throw std::runtime_error("goicp: no HIP device available (this engine has no CPU fallback)");
@@ -115,6 +120,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		rot_coeff_[l] = 2 * std::sin(maxAngle / 2);
 	}
 
+	lap("validation + device setup");
 	// ---- source cloud: (x,y,z,|p|), ordered for gather locality (morton_sort: 0 input order, 1 Morton curve, 2 k-d order) ----
 	{
 		std::vector<int32_t> perm(N_);
@@ -181,7 +187,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			};
 			// the top of the tree one split after the other, the (<= 16) ranges below in parallel
 			std::vector<std::pair<size_t, size_t>> ranges{{0, N_}};
-			while (N_ >= (1u << 16) && ranges.size() < 16) {
+			while (N_ >= (1u << 13) && ranges.size() < 16) {
 				std::vector<std::pair<size_t, size_t>> next;
 				for (auto [lo, hi] : ranges) {
 					const size_t nl = split(lo, hi);
@@ -207,6 +213,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		HIPCHK(hipMemcpy(d_src_, h_src_sorted_.data(), sizeof(float4) * N_, hipMemcpyHostToDevice));
 	}
 
+	lap("source order + upload");
 	// ---- distance transform geometry (jly_3ddt.cpp:891-923), double ----
 	{
 		double xMin = target[0], xMax = target[0], yMin = target[1], yMax = target[1], zMin = target[2], zMax = target[2];
@@ -274,6 +281,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		if (dt_.layout) HIPCHK(hipFree(d_work));
 		dt_build_ms_ = now_ms() - t0;
 	}
+	lap("distance transform");
 	// ---- k-d tree (64-ary box hierarchy) over the target ----
 	{
 		// auto = host median splits: at 1 M points the device (Morton) build is 0.3 s quicker to make, but its
@@ -310,6 +318,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		for (int l = 0; l < kMaxLevels; l++) kd_.boxes[l] = d_kd_boxes_[l];
 		kd_.pts = d_kd_pts_; kd_.M = (int)M_;
 	}
+	lap("k-d hierarchy + upload");
 	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)std::max(icp_blocks((int)N_), icp_trim_blocks((int)N_)) * kIcpAcc));
 	if (inliers_ < (int)N_) {
 		HIPCHK(hipMalloc(&d_nn_d2_, sizeof(float) * N_));
@@ -324,6 +333,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	std::memcpy(optR_, I, sizeof(I)); std::memcpy(curR_, I, sizeof(I)); std::memcpy(stepR_, I, sizeof(I));
 	std::memset(optT_, 0, sizeof(optT_)); std::memset(curT_, 0, sizeof(curT_)); std::memset(stepT_, 0, sizeof(stepT_));
 	publish(false);
+	lap("staging buffers");
 }
 
 Engine::~Engine() { release(); }

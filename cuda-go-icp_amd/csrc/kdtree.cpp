@@ -86,7 +86,7 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out)
 	constexpr int kTop = 16;
 	for (int n = 1; n < std::min(kTop, L); n++) split_node(n);
 	if (L > kTop)
-		parallel_tasks(M >= (1 << 16) ? kTop : 1, kTop, [&](int t) {
+		parallel_tasks(M >= (1 << 13) ? kTop : 1, kTop, [&](int t) {
 			for (int d = 0; ((kTop + t) << d) < L; d++)
 				for (int n = (kTop + t) << d; n < ((kTop + t + 1) << d); n++) split_node(n);
 		});

@@ -185,13 +185,15 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 					stack.push_back({lo, lo + nl});
 				}
 			};
-			// the top of the tree one split after the other, the (<= 16) ranges below in parallel
+			// the top of the tree level by level (its 1, 2, 4, 8 splits side by side), the (<= 16) ranges below in parallel
 			std::vector<std::pair<size_t, size_t>> ranges{{0, N_}};
 			while (N_ >= (1u << 13) && ranges.size() < 16) {
+				std::vector<size_t> nls(ranges.size());
+				parallel_tasks(16, (int)ranges.size(), [&](int t) { nls[t] = split(ranges[t].first, ranges[t].second); });
 				std::vector<std::pair<size_t, size_t>> next;
-				for (auto [lo, hi] : ranges) {
-					const size_t nl = split(lo, hi);
-					if (nl) { next.push_back({lo, lo + nl}); next.push_back({lo + nl, hi}); } else next.push_back({lo, hi});
+				for (size_t t = 0; t < ranges.size(); t++) {
+					const auto [lo, hi] = ranges[t];
+					if (nls[t]) { next.push_back({lo, lo + nls[t]}); next.push_back({lo + nls[t], hi}); } else next.push_back({lo, hi});
 				}
 				if (next.size() == ranges.size()) break;
 				ranges.swap(next);

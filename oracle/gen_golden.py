@@ -6,8 +6,9 @@ Runs only in the build container (needs /root/reference).  It
      they lie + oracle/ref_harness.cpp),
   2. runs the harness to produce the JSON fixtures (DT lookups, rotation radii, InnerBnB results,
      ICP3D::Run results, 3x3 SVD rotations, exact NN, three end-to-end registrations),
-  3. converts the reference's own input clouds (data/bunny/*.txt -- data files, not source) into
-     little-endian float32 blobs so that the GPU box, which has no /root/reference, can replay them.
+  3. converts the reference's own input clouds (data/bunny/*.txt, data/artec3d/data_skull.ply -- data
+     files, not source) into little-endian float32 blobs so that the GPU box, which has no
+     /root/reference, can replay them.
 
 usage: python oracle/gen_golden.py [--skip-full]     (full bunny e2e takes ~10 min of CPU)
 """
@@ -32,6 +33,18 @@ def txt_to_f32(harness, src, dst):
     return n
 
 
+def skull_to_f32(dst):
+    """data_skull.ply (98 359 points, the source of test/skull_goicp.toml; its target model_skull.ply is one of
+    the blobs missing from the reference checkout) through OUR loader with the config's resize = 0.01.  The
+    GPU test builds the registration problem from it as SURVEY 8d prescribes (known rigid motion)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    pkg = load_pkg()
+    c = pkg.load_cloud(os.path.join(REF, "data", "artec3d", "data_skull.ply"), 1.0, 0.01)
+    np.ascontiguousarray(c, dtype="<f4").tofile(dst)
+    return len(c)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -46,6 +59,7 @@ def main():
     for name, src in (("model_bunny", mb), ("data_bunny", db), ("model_rand", mr), ("data_rand", dr)):
         n = txt_to_f32(h, src, os.path.join(OUT, name + ".f32"))
         print(name, n, "points")
+    print("skull_scan", skull_to_f32(os.path.join(OUT, "skull_scan.f32")), "points")
     procs = [
         subprocess.Popen([h, "units", OUT, mb, db, "10"], stdout=subprocess.DEVNULL),
         subprocess.Popen([h, "trim", OUT, mb, db, "10", "0.1"], stdout=subprocess.DEVNULL),

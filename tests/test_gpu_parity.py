@@ -433,6 +433,32 @@ def test_fullsize_registration_recovers_ground_truth(pkg, s1):
     assert eng.get_best_error() < eng.sse_threshold
 
 
+def test_skull_scan_known_motion(pkg, oracle_mod):
+    """BASELINE configs[2] (skull_goicp.toml: larger cloud, k-d NN path stressed).  The config's target
+    model_skull.ply is missing from the reference checkout, so -- as SURVEY 8d prescribes -- the problem is
+    built from the scan the reference does hold (data_skull.ply, 98 359 points, resize 0.01; committed
+    fixture): target = the scan, source = a seeded 30 % subsample moved by a known rigid motion + N(0, 1e-3)
+    noise.  The motion must be recovered.  Parity with the reference is unpinned for this case (its CPU
+    run takes hours); the bar is the ground truth."""
+    target = cloud("skull_scan")
+    rng = np.random.default_rng(1234)
+    sub = target[rng.random(len(target)) < 0.3].astype(np.float64)
+    cx, sx, cy, sy, cz, sz = np.cos(1.3), np.sin(1.3), np.cos(-0.7), np.sin(-0.7), np.cos(2.1), np.sin(2.1)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    Rgt, tgt = Rz @ Ry @ Rx, np.array([0.15, -0.10, 0.05])
+    source = ((sub - tgt) @ Rgt + rng.normal(scale=1e-3, size=sub.shape)).astype(np.float32)   # target ~= Rgt source + tgt
+    eng = pkg.FastGoICP(target, source, 1e-3)
+    eng.run()
+    assert eng.finished and eng.get_best_error() < eng.sse_threshold
+    assert rot_angle(eng.optR, Rgt) <= 5e-3 and np.linalg.norm(eng.optT - tgt) <= 5e-3
+    # the exact NN operator on the same hierarchy (98 359 points: 8 192 leaves, three box levels)
+    q = np.concatenate([source[:1500], rng.uniform(-1.5, 1.5, (500, 3)).astype(np.float32)])
+    idx, d2 = eng.registration.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+
+
 def test_fullsize_nn_idempotent(pkg, s1):
     target, source, _, _ = s1
     reg = pkg.Registration(target, source[:64], 1e-3)

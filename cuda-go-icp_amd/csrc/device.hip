@@ -487,9 +487,10 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 //     the row's 16 lanes;
 //   * minima inside a row are DPP butterflies (quad_perm, row_half_mirror, row_mirror) -- no scalar
 //     loops, no LDS, no per-lane stack; "any lane of my row" is a slice of a ballot;
-//   * children are entered nearest-box-first and only while their box is within the best distance;
-//     the two nearest pending leaves are scanned per step (two loads in flight, one wait), and
-//     after every improvement the pending masks of all levels are re-filtered;
+//   * a child is one sortable key (distance bits | sub-index); children are TAKEN in ascending key
+//     order, so "next key above the best distance" means the group is exhausted -- no pending masks,
+//     no re-filtering; the two nearest remaining leaves are scanned per step (two loads in flight,
+//     one wait);
 //   * the search starts from the upper bound (|q - centre(v)| + DT[v] + 0.9 voxel)^2 read from the
 //     distance transform the engine already holds, so queries far from the surface prune as
 //     well as near ones; the nearest child of the root is fetched together with that seed;
@@ -499,7 +500,8 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 // wavefront per query with ballot/readlane loops 42 us (instruction-issue bound, ~1250
 // wave-instructions per query); this kernel 26 us (~440 per query; what is left is the chain of
 // dependent memory round trips of the slowest wavefront).
-// Depth K = 2 covers 64*64*16 = 65 536 target points, K = 3 up to 4.2 M.
+// The binary depth follows the cloud (full leaves, sparse root group, kdtree.cpp): K = 2 box levels up to
+// 65 536 target points, K = 3 up to 4.2 M.
 // Exactness: box lower bounds use the same monotone float accumulation as the point distances and
 // the boxes are exact, ties go to the lowest original index -> identical to a brute-force scan.
 // ------------------------------------------------------------------------------------------------

@@ -153,6 +153,58 @@ __device__ __forceinline__ void load_group(const CubeRec* __restrict__ cubes, co
 	}
 }
 
+// The clamped residuals max(DT(R p + t_c) - rho, 0) of one point under the 8 children of one expansion
+// (one rotation, per axis two translation values): 6 voxel indices instead of 24.  Every value is the same
+// float expression as in the generic per-cube path, so the results are bit-identical.
+struct SiblingSet { float tx0, tx1, ty0, ty1, tz0, tz1; };
+template <int LAYOUT>
+__device__ __forceinline__ void sibling_residuals(const DtDesc& dt, const Rot9& R0, const SiblingSet& t, const float4& p, float rho,
+                                                  float m[kGroup])
+{
+	const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
+	const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
+	const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+	const float qx[2] = {rx + t.tx0, rx + t.tx1}, qy[2] = {ry + t.ty0, ry + t.ty1}, qz[2] = {rz + t.tz0, rz + t.tz1};
+	bool risky = false;
+	int ix[2], iy[2], iz[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		ix[k] = voxel_fast(qx[k], dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+		iy[k] = voxel_fast(qy[k], dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
+		iz[k] = voxel_fast(qz[k], dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+	}
+	if (risky) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+			iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+			iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+		}
+	}
+	const unsigned fx[2] = {axis_offset<LAYOUT, 0>(dt, ix[0]), axis_offset<LAYOUT, 0>(dt, ix[1])};
+	const unsigned fy[2] = {axis_offset<LAYOUT, 1>(dt, iy[0]), axis_offset<LAYOUT, 1>(dt, iy[1])};
+	const unsigned fz[2] = {axis_offset<LAYOUT, 2>(dt, iz[0]), axis_offset<LAYOUT, 2>(dt, iz[1])};
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) {
+		const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
+		float v;
+		if (e < kOutside) v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
+		else v = dt_distance<LAYOUT>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);   // clamp + overshoot extension
+		v = v - rho;
+		m[c] = v < 0.f ? 0.f : v;
+	}
+}
+// do the 8 records describe the children of one expansion?  (jly_goicp.cpp:267-273: corner + bit*w + w/2)
+__device__ __forceinline__ bool is_sibling_set(const CubeRec cr[kGroup])
+{
+	bool sib = true;
+#pragma unroll
+	for (int c = 0; c < kGroup; c++)
+		sib = sib && cr[c].rot == cr[0].rot && cr[c].tx == cr[c & 1].tx && cr[c].ty == cr[c & 2].ty && cr[c].tz == cr[c & 4].tz &&
+		      cr[c].delta == cr[0].delta && cr[c].coeff == cr[0].coeff;
+	return sib;
+}
+
 // ------------------------------------------------------------------------------------------------
 // (a) cube bounds
 // ------------------------------------------------------------------------------------------------
@@ -204,44 +256,16 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 	if (siblings) {
 		// fast path: 6 voxel-index computations per point instead of 24; every per-point value is the
 		// same float expression as in the generic path below, so the results are bit-identical
-		const float tx0 = cr[0].tx, tx1 = cr[1].tx, ty0 = cr[0].ty, ty1 = cr[2].ty, tz0 = cr[0].tz, tz1 = cr[4].tz;
+		const SiblingSet ts{cr[0].tx, cr[1].tx, cr[0].ty, cr[2].ty, cr[0].tz, cr[4].tz};
 		const float delta = cr[0].delta, coeff = cr[0].coeff;
 		for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
 			const float4 p = src[i];
-			const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
-			const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
-			const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
-			const float rho = coeff * p.w;
-			const float qx[2] = {rx + tx0, rx + tx1}, qy[2] = {ry + ty0, ry + ty1}, qz[2] = {rz + tz0, rz + tz1};
-			bool risky = false;
-			int ix[2], iy[2], iz[2];
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				ix[k] = voxel_fast(qx[k], dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
-				iy[k] = voxel_fast(qy[k], dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
-				iz[k] = voxel_fast(qz[k], dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
-			}
-			if (risky) {
-#pragma unroll
-				for (int k = 0; k < 2; k++) {
-					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
-					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
-					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
-				}
-			}
-			const unsigned fx[2] = {axis_offset<LAYOUT, 0>(dt, ix[0]), axis_offset<LAYOUT, 0>(dt, ix[1])};
-			const unsigned fy[2] = {axis_offset<LAYOUT, 1>(dt, iy[0]), axis_offset<LAYOUT, 1>(dt, iy[1])};
-			const unsigned fz[2] = {axis_offset<LAYOUT, 2>(dt, iz[0]), axis_offset<LAYOUT, 2>(dt, iz[1])};
+			float m[kGroup];
+			sibling_residuals<LAYOUT>(dt, R0, ts, p, coeff * p.w, m);
 #pragma unroll
 			for (int c = 0; c < kGroup; c++) {
-				const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
-				float m;
-				if (e < kOutside) m = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
-				else m = dt_distance<LAYOUT>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);   // clamp + overshoot extension
-				m = m - rho;
-				if (m < 0.f) m = 0.f;
-				ub[c] += m * m;
-				const float dis = fmaxf(m - delta, 0.f);
+				ub[c] += m[c] * m[c];
+				const float dis = fmaxf(m[c] - delta, 0.f);
 				lb[c] += dis * dis;
 			}
 		}
@@ -313,47 +337,62 @@ __global__ void bounds_finalize(const float* __restrict__ scratch, int B, int gr
 // every pass instead of storing B x N floats; a fourth pass sums the residuals below the threshold
 // T, and the `rem` copies of T itself are added once.
 // ------------------------------------------------------------------------------------------------
+// One workgroup of 1024 threads per expansion: it sweeps the whole cloud four times, and with a single
+// workgroup per CU only its own wavefronts can hide the gather latency.
+constexpr int kTrimThreads = 1024;
 template <int LAYOUT>
-__global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
+__global__ __launch_bounds__(kTrimThreads) void bounds_trim_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int inliers,
     float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	__shared__ unsigned hist[kGroup][2048];
 	__shared__ unsigned sel_prefix[kGroup], sel_rem[kGroup];
-	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
+	__shared__ float red[kTrimThreads / 64][2 * kGroup];
 	const int c0 = blockIdx.x * kGroup;
 	CubeRec cr[kGroup];
 	load_group(cubes, parents, blockIdx.x, B, cr);
 	if (threadIdx.x < kGroup) { sel_prefix[threadIdx.x] = 0u; sel_rem[threadIdx.x] = (unsigned)inliers; }
 
-	auto residual = [&](const float4& p, int c) -> float {
-		const Rot9 R = rots[cr[c].rot];
-		const float rx = R.r[0] * p.x + R.r[1] * p.y + R.r[2] * p.z;
-		const float ry = R.r[3] * p.x + R.r[4] * p.y + R.r[5] * p.z;
-		const float rz = R.r[6] * p.x + R.r[7] * p.y + R.r[8] * p.z;
-		float m = dt_distance<LAYOUT>(dt, rx + cr[c].tx, ry + cr[c].ty, rz + cr[c].tz);
-		m = m - cr[c].coeff * p.w;
-		return m < 0.f ? 0.f : m;
+	// the 8 clamped residuals of one point: the sibling form (one rotation, 6 voxel indices) for an expansion,
+	// the per-cube form for anything else; same values either way
+	const bool sib = is_sibling_set(cr) && c0 + kGroup <= B;
+	const Rot9 R0 = rots[cr[0].rot];
+	const SiblingSet ts{cr[0].tx, cr[1].tx, cr[0].ty, cr[2].ty, cr[0].tz, cr[4].tz};
+	auto residuals = [&](const float4& p, float m[kGroup]) {
+		if (sib) { sibling_residuals<LAYOUT>(dt, R0, ts, p, cr[0].coeff * p.w, m); return; }
+#pragma unroll
+		for (int c = 0; c < kGroup; c++) {
+			const Rot9 R = rots[cr[c].rot];
+			const float rx = R.r[0] * p.x + R.r[1] * p.y + R.r[2] * p.z;
+			const float ry = R.r[3] * p.x + R.r[4] * p.y + R.r[5] * p.z;
+			const float rz = R.r[6] * p.x + R.r[7] * p.y + R.r[8] * p.z;
+			float v = dt_distance<LAYOUT>(dt, rx + cr[c].tx, ry + cr[c].ty, rz + cr[c].tz);
+			v = v - cr[c].coeff * p.w;
+			m[c] = v < 0.f ? 0.f : v;
+		}
 	};
 
 #pragma unroll 1
 	for (int pass = 0; pass < 3; pass++) {
 		const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), width = pass == 2 ? 9 : 11, bins = 1 << width;
-		for (int i = threadIdx.x; i < kGroup * 2048; i += kBoundsThreads) (&hist[0][0])[i] = 0u;
+		for (int i = threadIdx.x; i < kGroup * 2048; i += kTrimThreads) (&hist[0][0])[i] = 0u;
 		__syncthreads();
-		for (int i = threadIdx.x; i < N; i += kBoundsThreads) {
+		for (int i = threadIdx.x; i < N; i += kTrimThreads) {
 			const float4 p = src[i];
+			float m[kGroup];
+			residuals(p, m);
 #pragma unroll
 			for (int c = 0; c < kGroup; c++) {
-				const unsigned key = __float_as_uint(residual(p, c));
+				const unsigned key = __float_as_uint(m[c]);
 				if (pass == 0 || (key >> (shift + width)) == sel_prefix[c])
 					atomicAdd(&hist[c][(key >> shift) & (unsigned)(bins - 1)], 1u);
 			}
 		}
 		__syncthreads();
-		// 32 threads per cube: locate the bin holding the rem-th smallest of the surviving candidates
-		{
+		// 32 threads per cube (the first four wavefronts): locate the bin holding the rem-th smallest of the
+		// surviving candidates
+		if (threadIdx.x < 32 * kGroup) {
 			const int c = threadIdx.x >> 5, j = threadIdx.x & 31, per = bins >> 5;
 			unsigned local = 0;
 			for (int b = j * per; b < (j + 1) * per; b++) local += hist[c][b];
@@ -383,14 +422,15 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
 	float ub[kGroup], lb[kGroup];
 #pragma unroll
 	for (int c = 0; c < kGroup; c++) { ub[c] = 0.f; lb[c] = 0.f; }
-	for (int i = threadIdx.x; i < N; i += kBoundsThreads) {
+	for (int i = threadIdx.x; i < N; i += kTrimThreads) {
 		const float4 p = src[i];
+		float m[kGroup];
+		residuals(p, m);
 #pragma unroll
 		for (int c = 0; c < kGroup; c++) {
-			const float m = residual(p, c);
-			if (__float_as_uint(m) < sel_prefix[c]) {        // strictly below the k-th smallest
-				ub[c] += m * m;
-				const float dis = fmaxf(m - cr[c].delta, 0.f);
+			if (__float_as_uint(m[c]) < sel_prefix[c]) {     // strictly below the k-th smallest
+				ub[c] += m[c] * m[c];
+				const float dis = fmaxf(m[c] - cr[c].delta, 0.f);
 				lb[c] += dis * dis;
 			}
 		}
@@ -405,7 +445,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_trim_kernel(
 	if (threadIdx.x < 2 * kGroup) {
 		float s = red[0][threadIdx.x];
 #pragma unroll
-		for (int w = 1; w < kBoundsThreads / 64; w++) s += red[w][threadIdx.x];
+		for (int w = 1; w < kTrimThreads / 64; w++) s += red[w][threadIdx.x];
 		const int c = threadIdx.x & (kGroup - 1);
 		// the residuals equal to the threshold: sel_rem copies of T
 		const float T = __uint_as_float(sel_prefix[c]);
@@ -424,7 +464,7 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
                               int inliers, float* ub, float* lb, hipStream_t stream)
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
-	const dim3 grid((B + kGroup - 1) / kGroup), block(kBoundsThreads);
+	const dim3 grid((B + kGroup - 1) / kGroup), block(kTrimThreads);
 	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
 	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
 	return hipGetLastError();
@@ -770,49 +810,161 @@ __global__ __launch_bounds__(kIcpThreads) void icp_nn_kernel(const float4* __res
 
 // one workgroup: key of the num-th smallest d2 (3-digit radix select), then inclusion flags with the
 // ties taken in point order (deterministic)
-__global__ __launch_bounds__(1024) void icp_select_kernel(const float* __restrict__ nn_d2, int N, int num,
+__global__ __launch_bounds__(1024) void icp_select_stream_kernel(const float* __restrict__ nn_d2, int N, int num,
                                                           const IcpState* __restrict__ st, unsigned char* __restrict__ include)
 {
 	if (st->converged) return;
 	__shared__ unsigned hist[2048];
-	__shared__ unsigned sel_prefix, sel_rem, wave_cnt[16], tie_base;
-	if (threadIdx.x == 0) { sel_prefix = 0u; sel_rem = (unsigned)num; tie_base = 0u; }
+	__shared__ unsigned sel_prefix, sel_rem, wave_cnt[16], wave_tot[16];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) { sel_prefix = 0u; sel_rem = (unsigned)num; }
 #pragma unroll 1
 	for (int pass = 0; pass < 3; pass++) {
 		const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), width = pass == 2 ? 9 : 11, bins = 1 << width;
 		for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0u;
 		__syncthreads();
-		for (int i = threadIdx.x; i < N; i += 1024) {
-			const unsigned key = __float_as_uint(nn_d2[i]);
-			if (pass == 0 || (key >> (shift + width)) == sel_prefix) atomicAdd(&hist[(key >> shift) & (unsigned)(bins - 1)], 1u);
+		const unsigned prefix = sel_prefix;
+		for (int base = 0; base < N; base += 1024) {
+			const int i = base + threadIdx.x;
+			const unsigned key = i < N ? __float_as_uint(nn_d2[i]) : 0u;
+			bool live = i < N && (pass == 0 || (key >> (shift + width)) == prefix);
+			const unsigned bin = (key >> shift) & (unsigned)(bins - 1);
+			if (live) atomicAdd(&hist[bin], 1u);      // same-address lanes serialise inside LDS (<= 64 cycles per instruction): cheap from registers
 		}
 		__syncthreads();
-		if (threadIdx.x == 0) {     // 2048 bins, once per pass: a serial scan is negligible next to the N-element passes
-			unsigned cum = 0, rem = sel_rem;
-			for (int b = 0; b < bins; b++) {
-				const unsigned h = hist[b];
-				if (cum < rem && rem <= cum + h) { sel_prefix = (sel_prefix << width) | (unsigned)b; sel_rem = rem - cum; break; }
-				cum += h;
+		// the bin holding the rem-th smallest candidate: two bins per thread, wavefront scan, 16 wavefront totals
+		{
+			const unsigned h0 = hist[2 * threadIdx.x], h1 = hist[2 * threadIdx.x + 1];   // bins beyond `bins` are zero
+			const unsigned local = h0 + h1;
+			unsigned incl = local;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const unsigned o = __shfl_up(incl, off, 64);
+				if (lane >= off) incl += o;
+			}
+			if (lane == 63) wave_tot[wave] = incl;
+			__syncthreads();
+			unsigned before = 0;
+			for (int w2 = 0; w2 < wave; w2++) before += wave_tot[w2];
+			const unsigned excl = before + incl - local, rem = sel_rem;
+			__syncthreads();                                  // every thread has read sel_rem before one rewrites it
+			if (excl < rem && rem <= excl + local) {              // exactly one thread
+				const bool first = rem <= excl + h0;
+				sel_prefix = (prefix << width) | (unsigned)(2 * threadIdx.x + (first ? 0 : 1));
+				sel_rem = rem - (first ? excl : excl + h0);
 			}
 		}
 		__syncthreads();
 	}
+	// inclusion flags; the sel_rem copies of the threshold itself go to the ties that come first in point
+	// order: every thread owns a contiguous run of points, counts its ties, one block scan orders them
 	const unsigned T = sel_prefix, rem = sel_rem;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (int base = 0; base < N; base += 1024) {
-		const int i = base + threadIdx.x;
-		const unsigned key = i < N ? __float_as_uint(nn_d2[i]) : 0xffffffffu;
+	const int per = (N + 1023) / 1024, lo = min((int)threadIdx.x * per, N), hi = min(lo + per, N);
+	unsigned mine = 0;
+	for (int i = lo; i < hi; i++) mine += __float_as_uint(nn_d2[i]) == T ? 1u : 0u;
+	unsigned incl = mine;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const unsigned o = __shfl_up(incl, off, 64);
+		if (lane >= off) incl += o;
+	}
+	if (lane == 63) wave_cnt[wave] = incl;
+	__syncthreads();
+	unsigned before = incl - mine;
+	for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2];
+	for (int i = lo; i < hi; i++) {
+		const unsigned key = __float_as_uint(nn_d2[i]);
 		const bool tie = key == T;
+		include[i] = (key < T || (tie && before < rem)) ? 1 : 0;
+		before += tie ? 1u : 0u;
+	}
+}
+
+// The same selection for N <= 32 768 with the distances held in registers (32 per thread, one burst of
+// loads): a single workgroup streaming them from memory three times is a chain of ~90 dependent loads
+// (160 us at bunny size); from registers the three digit passes touch only LDS.
+constexpr int kSelPer = 32;
+__global__ __launch_bounds__(1024) void icp_select_kernel(const float* __restrict__ nn_d2, int N, int num,
+                                                          const IcpState* __restrict__ st, unsigned char* __restrict__ include)
+{
+	__shared__ unsigned hist[2048];
+	__shared__ unsigned sel_prefix, sel_rem, wave_tot[16];
+	__shared__ unsigned short tie_cnt[kSelPer][16];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	unsigned key[kSelPer];
+#pragma unroll
+	for (int j = 0; j < kSelPer; j++) {
+		const int i = j * 1024 + (int)threadIdx.x;
+		key[j] = i < N ? __float_as_uint(nn_d2[i]) : 0xffffffffu;      // padding sorts last (distances are >= 0 and finite)
+	}
+	if (st->converged) return;
+	if (threadIdx.x == 0) { sel_prefix = 0u; sel_rem = (unsigned)num; }
+#pragma unroll 1
+	for (int pass = 0; pass < 3; pass++) {
+		const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0), width = pass == 2 ? 9 : 11, bins = 1 << width;
+		for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0u;
+		__syncthreads();
+		const unsigned prefix = sel_prefix;
+#pragma unroll
+		for (int j = 0; j < kSelPer; j++) {
+			const bool live = j * 1024 + (int)threadIdx.x < N && (pass == 0 || (key[j] >> (shift + width)) == prefix);
+			const unsigned bin = (key[j] >> shift) & (unsigned)(bins - 1);
+			if (live) atomicAdd(&hist[bin], 1u);      // same-address lanes serialise inside LDS (<= 64 cycles per instruction): cheap from registers
+		}
+		__syncthreads();
+		// the bin holding the rem-th smallest candidate: two bins per thread, wavefront scan, 16 wavefront totals
+		const unsigned h0 = hist[2 * threadIdx.x], h1 = hist[2 * threadIdx.x + 1];       // bins beyond `bins` are zero
+		const unsigned local = h0 + h1;
+		unsigned incl = local;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned o = __shfl_up(incl, off, 64);
+			if (lane >= off) incl += o;
+		}
+		if (lane == 63) wave_tot[wave] = incl;
+		__syncthreads();
+		unsigned before = 0;
+		for (int w2 = 0; w2 < wave; w2++) before += wave_tot[w2];
+		const unsigned excl = before + incl - local, rem = sel_rem;
+		__syncthreads();                                      // every thread has read sel_rem before one rewrites it
+		if (excl < rem && rem <= excl + local) {                  // exactly one thread
+			const bool first = rem <= excl + h0;
+			sel_prefix = (prefix << width) | (unsigned)(2 * threadIdx.x + (first ? 0 : 1));
+			sel_rem = rem - (first ? excl : excl + h0);
+		}
+		__syncthreads();
+	}
+	// inclusion flags; the sel_rem copies of the threshold itself go to the ties that come first in point order
+	// (i = j*1024 + thread): per (j, wavefront) tie counts, one barrier, then every lane ranks its own ties
+	const unsigned T = sel_prefix, rem = sel_rem;
+#pragma unroll
+	for (int j = 0; j < kSelPer; j++) {
+		const unsigned long long tb = __ballot(key[j] == T);
+		if (lane == 0) tie_cnt[j][wave] = (unsigned short)__popcll(tb);
+	}
+	__syncthreads();
+	// lane j gathers, for iteration j, the ties of the earlier iterations and of the earlier wavefronts
+	unsigned wbefore = 0, total = 0;
+	if (lane < kSelPer)
+		for (int w2 = 0; w2 < 16; w2++) {
+			const unsigned c = tie_cnt[lane][w2];
+			total += c;
+			wbefore += w2 < wave ? c : 0u;
+		}
+	unsigned incl = total;
+#pragma unroll
+	for (int off = 1; off < kSelPer; off <<= 1) {
+		const unsigned o = __shfl_up(incl, off, 64);
+		if (lane >= off) incl += o;
+	}
+	const unsigned base = incl - total + wbefore;
+#pragma unroll
+	for (int j = 0; j < kSelPer; j++) {
+		const int i = j * 1024 + (int)threadIdx.x;
+		const bool tie = key[j] == T;
 		const unsigned long long tb = __ballot(tie);
-		if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(tb);
-		__syncthreads();
-		unsigned before = tie_base;
-		for (int w2 = 0; w2 < wave; w2++) before += wave_cnt[w2];
-		before += (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
-		if (i < N) include[i] = (key < T || (tie && before < rem)) ? 1 : 0;
-		__syncthreads();
-		if (threadIdx.x == 0) { unsigned t = 0; for (int w2 = 0; w2 < 16; w2++) t += wave_cnt[w2]; tie_base += t; }
-		__syncthreads();
+		const unsigned rank = (unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
+		if (i < N) include[i] = (key[j] < T || (tie && rank < rem)) ? 1 : 0;
 	}
 }
 
@@ -1064,7 +1216,8 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 	if (kd.K == 1) launch_nn_store_k<1>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
 	else if (kd.K == 2) launch_nn_store_k<2>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
 	else launch_nn_store_k<3>(src, N, st, kd, dt, nn_d2, nn_slot, stream);
-	hipLaunchKernelGGL(icp_select_kernel, dim3(1), dim3(1024), 0, stream, nn_d2, N, num, st, include);
+	if (N <= 1024 * kSelPer) hipLaunchKernelGGL(icp_select_kernel, dim3(1), dim3(1024), 0, stream, nn_d2, N, num, st, include);
+	else hipLaunchKernelGGL(icp_select_stream_kernel, dim3(1), dim3(1024), 0, stream, nn_d2, N, num, st, include);
 	const int nb = icp_trim_blocks(N);
 	hipLaunchKernelGGL(icp_accum_kernel, dim3(nb), dim3(kIcpThreads), 0, stream, src, N, st, kd, nn_d2, nn_slot, include, partials);
 	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, nb, st);

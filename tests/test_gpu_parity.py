@@ -625,6 +625,26 @@ def test_gpu_built_hierarchy_e2e(pkg, bunny_model, bunny_data10):
 # ----------------------------------------------------------------------------------------------
 # result API under concurrency (the reference's viewer polls the worker: src/goicp_kernel.cu:161-177)
 # ----------------------------------------------------------------------------------------------
+def test_rerun_and_concurrent_engines(pkg, bunny_model, bunny_data10):
+    """An engine can register again (same answer, bit for bit), and two engines of one process running at the
+    same time on their own streams do not disturb each other (no shared mutable state in the library)."""
+    import threading
+    a = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3)
+    a.run()
+    first = (a.get_best_error(), a.optR.copy(), a.optT.copy(), a.registration.poll().counters.cubes)
+    a.run()
+    again = (a.get_best_error(), a.optR.copy(), a.optT.copy(), a.registration.poll().counters.cubes)
+    assert first[0] == again[0] and np.array_equal(first[1], again[1]) and np.array_equal(first[2], again[2]) and first[3] == again[3]
+    engines = [pkg.FastGoICP(bunny_model, bunny_data10, 1e-3) for _ in range(3)]
+    threads = [threading.Thread(target=e.run) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        assert e.finished and e.get_best_error() == first[0] and np.array_equal(e.optR, first[1]) and np.array_equal(e.optT, first[2])
+
+
 def test_poll_and_cancel_while_running(pkg, bunny_model, bunny_data):
     """goicp_poll from another thread returns consistent snapshots (best error never increases, optR stays
     a rotation) while goicp_register runs; goicp_cancel (the reference's `goicp_finished` flag) stops it."""

@@ -62,6 +62,28 @@ def make_batch(pkg, reg, n_expansions, n_rot, seed):
     return rots, recs, n_lb
 
 
+def make_generic_batch(pkg, reg, n_cubes, n_rot, seed):
+    """SURVEY 8(d)'s microbench batch: independent translation cubes (centres U[-0.5,0.5]^3, half-width 1/64), rotations
+    uniform in the pi-ball, every second cube a lower-bound pass.  No two cubes of a workgroup are siblings, so the
+    kernel takes its generic path (24 voxel-index computations per point instead of 6)."""
+    rng = np.random.default_rng(seed)
+    rv = []
+    while len(rv) < n_rot:
+        v = rng.uniform(-np.pi, np.pi, 3)
+        if np.linalg.norm(v) <= np.pi:
+            rv.append(v)
+    rots = np.stack([pkg.fgoicp.rodrigues(v) for v in rv]).astype(np.float32)
+    recs = np.zeros(n_cubes, dtype=[("tx", "<f4"), ("ty", "<f4"), ("tz", "<f4"), ("delta", "<f4"), ("coeff", "<f4"), ("rot", "<i4")])
+    c = rng.uniform(-0.5, 0.5, (n_cubes, 3)).astype(np.float32)
+    recs["tx"], recs["ty"], recs["tz"] = c[:, 0], c[:, 1], c[:, 2]
+    recs["delta"] = np.float32(reg._lib.goicp_trans_delta(1.0 / 32))          # child width 1/32 = half-width 1/64
+    lb_pass = (np.arange(n_cubes) % 2) == 1
+    coeff = np.array([float(reg.rot_coeff(int(l))) for l in range(20)], np.float32)
+    recs["coeff"] = np.where(lb_pass, coeff[rng.integers(3, 9, n_cubes)], np.float32(0))
+    recs["rot"] = rng.integers(0, n_rot, n_cubes)
+    return rots, recs, int(lb_pass.sum())
+
+
 def cpu_baseline(reg, model, data, seconds=6.0):
     """The CPU oracle (a port of the reference's InnerBnB body) on the same DT, 1 thread and all cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -89,18 +111,35 @@ def cpu_baseline(reg, model, data, seconds=6.0):
     return out
 
 
+REF_FLAGS = ("jly_goicp.cpp, matrix.cpp and DT3D::Distance (jly_3ddt.cpp): g++ -O3 -DNDEBUG = the reference's CMake Release default "
+             "(CMakeLists.txt:20-23); DT3D::Build and the rest of jly_3ddt.cpp: -O0 (its Release build corrupts 2.7 % of the voxels, "
+             "SURVEY A.3) -- the build is outside the timed region")
+
+
 def reference_baseline(seconds=10.0):
-    """oracle/_ref/ref_harness (the REAL reference CPU Go-ICP, compiled from its sources by oracle/Makefile in the
-    build container; it travels with the snapshot): the reference's own InnerBnB on the fixture clouds, timed
-    on this host.  None when the binary is not there."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    """oracle/_ref/ref_harness_bench (the REAL reference CPU Go-ICP at its Release flags, compiled from its sources by
+    oracle/Makefile in the build container; it travels with the snapshot): the reference's own GoICP::InnerBnB on the
+    fixture clouds, timed on this host.  The exact number of cube bounds of the seeded call sequence comes from
+    tests/golden/ref_bench_counts.json (DT3D::Distance calls / Nd, counted once by oracle/_ref/ref_harness_count);
+    it is used only when the reference's own tNodeCount of this run matches the table.  None when the binary is not there."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_bench")
     g = os.path.join(ROOT, "tests", "golden")
     if not os.path.exists(exe):
         return None
     try:
         r = subprocess.run([exe, "bench", os.path.join(g, "model_bunny.f32"), os.path.join(g, "data_bunny.f32"), str(seconds)],
-                           capture_output=True, text=True, timeout=240)
-        return json.loads(r.stdout.strip().splitlines()[-1])
+                           capture_output=True, text=True, timeout=300)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["cube_bounds"], out["count"] = out["cube_bounds_upper"], "8 x tNodeCount (upper bound: counts each call's final non-expanding pop)"
+        tab_path = os.path.join(g, "ref_bench_counts.json")
+        if os.path.exists(tab_path):
+            with open(tab_path) as f:
+                tab = json.load(f)
+            k = out["inner_bnb_calls"]
+            if k < len(tab["pops_prefix"]) and tab["pops_prefix"][k] == out["trans_pops"]:
+                out["cube_bounds"], out["count"] = tab["cube_bounds_prefix"][k], "exact (DT3D::Distance calls / Nd, tests/golden/ref_bench_counts.json; tNodeCount of this run matches the table)"
+        out["cube_bounds_per_s"] = out["cube_bounds"] / out["seconds"]
+        return out
     except Exception as e:                      # a baseline leg must never take the GPU measurement down
         print("reference baseline unavailable: %r" % (e,), file=sys.stderr)
         return None
@@ -262,24 +301,67 @@ def main():
         # ---- roofline of the dominant kernel: HIP events on the launch stream, live ----
         ms = C.c_float()
         B.check(lib.goicp_time_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), 10, C.byref(ms)))
-        alg_bytes = (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N      # 16N ub pass, 20N lb pass
-        achieved = alg_bytes / (ms.value * 1e-3) / 1e9
-        # HBM-side traffic of the same launch: PMC counters cannot be read from inside this process; they
-        # were collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and
-        # WRITE_SIZE, gfx950 x2 correction on FETCH_SIZE) and are committed under profiles/
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_bounds.json")
-        if args.workload == "bunny" and args.dt_size == 300 and Bc == 65536 and os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_e_pmc_bounds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; fabric-side of L2, includes Infinity-Cache hits)"
-        roofline = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "launch_ms": round(ms.value, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                    "cube_bounds_per_s_kernel": round(Bc / (ms.value * 1e-3), 1)}
-        if traffic is not None:     # the committed counters belong to exactly this workload
-            roofline["limiter"] = ("cloud and DT are cache-resident at this size: the texture-address units are 100 % busy "
-                                   "(TA_TA_BUSY_sum in profiles/r01_e_pmc_bounds.json), 27.9 cycles per 64-lane gather instruction against a floor of 16")
+        launch_s = ms.value * 1e-3
+        # The kernel is NOT HBM-bound at these sizes (cloud + DT are cache-resident, 95 % L2 hits): the PMC counters say
+        # the vector-memory address / L1 path is busy for the whole kernel.  Its ceiling is therefore
+        # measured, in this run, by a probe kernel that only issues independent 4-byte loads into the same resident DT
+        # (goicp_probe_gather): coalesced / fully divergent, from an L1-sized, an L2-sized and the whole-grid window.
+        probe = {}
+        for name, mode, window in (("coalesced_l1", 0, 16 << 10), ("coalesced_l2", 0, 2 << 20), ("coalesced_dt", 0, 1 << 40),
+                                   ("divergent_l1", 1, 16 << 10), ("divergent_l2", 1, 2 << 20), ("divergent_dt", 1, 1 << 40)):
+            v = C.c_double()
+            B.check(lib.goicp_probe_gather(h, mode, window, C.byref(v)))
+            probe[name] = round(v.value / 1e9, 2)
+        lookups = float(Bc) * N                                    # one DT lookup per (cube, point)
+        glook = lookups / launch_s / 1e9
+        peak = probe["coalesced_l1"]
+        # algorithmic bytes: SURVEY 8(d)'s no-reuse model (16 N ub pass / 20 N lb pass) and the kernel as built
+        # (a point's 16 B are loaded once per 8 sibling cubes = 2 N per cube bound, + 4 N of DT voxels)
+        alg_bytes = (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N
+        built_bytes = Bc * (2.0 + 4.0) * N
+        # HBM-side traffic of the same launch: PMC counters cannot be read from inside this process; they are
+        # collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and WRITE_SIZE,
+        # gfx950 x2 correction on FETCH_SIZE) and committed under profiles/
+        traffic, traffic_src, limiter = None, None, None
+        for cand in ("r02_pmc_bounds_%s.json" % args.workload, "r01_e_pmc_bounds.json" if args.workload == "bunny" else ""):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if cand and Bc == 65536 and args.dt_size == (300 if args.workload != "s2" else 512) and os.path.exists(pmc):
+                with open(pmc) as f:
+                    j = json.load(f)
+                traffic = j["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; fabric side of L2, Infinity-Cache hits included: an upper bound on HBM bytes)" % cand
+                limiter = j.get("limiter")
+                break
+        roofline = {"bound": "l1-gather", "kernel": "goicp::bounds_kernel", "achieved": round(glook, 2), "peak": peak, "unit": "Glookup/s",
+                    "frac": round(glook / peak, 4),
+                    "peak_source": "goicp_probe_gather in this run: independent coalesced 4-B loads from a 16 KiB window per workgroup of the resident DT",
+                    "probe_Glookup_per_s": probe,
+                    "frac_of_divergent_l2_probe": round(glook / probe["divergent_l2"], 4),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "traffic_GBs": None if traffic is None else round(traffic / launch_s / 1e9, 1),
+                            "frac": None if traffic is None else round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                            "algorithmic_GBs_survey_model": round(alg_bytes / launch_s / 1e9, 1),
+                            "algorithmic_GBs_as_built": round(built_bytes / launch_s / 1e9, 1),
+                            "note": "SURVEY 8(d) prices a cube bound at 16 N / 20 N bytes (no reuse); the kernel loads a point once per 8 sibling cubes "
+                                    "(2 N + 4 N bytes per cube bound) and both operands are cache-resident, so bytes per second against the HBM peak is "
+                                    "not a ceiling for this kernel -- informational only"},
+                    "launch_ms": round(ms.value, 4), "lookups_per_launch": lookups,
+                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_launch_as_built": built_bytes,
+                    "cube_bounds_per_s_kernel": round(Bc / launch_s, 1)}
+        if limiter:
+            roofline["limiter"] = limiter
+        # ---- the generic path: SURVEY 8(d)'s batch of unrelated cubes through the same entry point ----
+        g_rots, g_recs, g_nlb = make_generic_batch(pkg, reg, Bc, 8, seed=99)
+        gd_rots = torch.from_numpy(g_rots.reshape(-1)).to(dev)
+        gd_cubes = torch.from_numpy(g_recs.view(np.uint8).reshape(-1)).to(dev)
+        gms = C.c_float()
+        B.check(lib.goicp_time_bounds_device(h, gd_rots.data_ptr(), gd_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(gms)))
+        generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
+                   "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
+                   "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}
+        B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))   # restore the headline batch's outputs
+        torch.cuda.synchronize()
         # ---- what this GPU's HBM actually streams (device-to-device copy of 2 GiB, read + write counted) ----
         a_ = torch.empty(1 << 29, dtype=torch.float32, device=dev); b_ = torch.empty_like(a_)
         b_.copy_(a_); torch.cuda.synchronize()
@@ -324,10 +406,11 @@ def main():
                     "icp_iters_per_s_1thread": round(c["icp_iters_per_s_1thread"], 2)}
             ref = reference_baseline() if args.workload == "bunny" else None
             if ref:
-                cpu = {"value": ref["cube_bounds_per_s"], "unit": "cube-bounds/s", "cores": 1, "kind": "reference",
-                       "sample": "oracle/_ref/ref_harness bench: the reference's own GoICP::InnerBnB (jly_goicp.cpp, -O2) on the same clouds, "
-                                 "%d alternating ub/lb searches over seeded rotations in %.1f s = %d translation nodes x 8 children; "
-                                 "its DT build (%.1f s) is outside the timed region" % (ref["inner_bnb_calls"], ref["seconds"], ref["trans_pops"], ref["dt_build_s"]),
+                cpu = {"value": round(ref["cube_bounds_per_s"], 1), "unit": "cube-bounds/s", "cores": 1, "kind": "reference",
+                       "sample": "oracle/_ref/ref_harness_bench: the reference's own GoICP::InnerBnB on the same clouds, %d alternating ub/lb searches over "
+                                 "seeded rotations in %.1f s = %d cube bounds [%s] (%d translation-node pops); its DT build (%.1f s) is outside the timed "
+                                 "region.  Flags per TU: %s" % (ref["inner_bnb_calls"], ref["seconds"], ref["cube_bounds"], ref["count"], ref["trans_pops"],
+                                                                ref["dt_build_s"], REF_FLAGS),
                        "reference_dt_build_s": ref["dt_build_s"]}
             else:
                 cpu = {"value": port["port_value"], "unit": "cube-bounds/s", "cores": 1, "kind": "port", "sample": port["port_sample"]}
@@ -339,7 +422,7 @@ def main():
                "config": {"workload": "%s: N=%d source, M=%d target, DT %d^3, subsample 1.0" % (wname, N, M, V),
                           "cubes_per_step_per_gpu": Bc, "lb_pass_fraction": n_lb / Bc, "rotations_per_step": 8,
                           "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) best ub" if world > 1 else "local min"},
-               "roofline": roofline, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": sharded_res}
+               "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": sharded_res}
         print(json.dumps(out), flush=True)
     reg.close()
     if world > 1:

@@ -25,14 +25,16 @@ class CConfig(C.Structure):
                 ("viz_theta", C.c_float), ("viz_phi", C.c_float), ("viz_spin_after_finish", C.c_int32),
                 ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3), ("rot_search_depth", C.c_int32),
                 ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("trans_search_depth", C.c_int32),
-                ("description", C.c_char * PATH_MAX)]
+                ("description", C.c_char * PATH_MAX), ("has_rotation_range", C.c_int32), ("has_translation_range", C.c_int32)]
 
 
 class CParams(C.Structure):
     _fields_ = [("dt_size", C.c_int32), ("dt_expand", C.c_double), ("mse_threshold", C.c_float),
                 ("dt_layout", C.c_int32), ("device", C.c_int32), ("trans_batch", C.c_int32),
                 ("wide_children", C.c_int32), ("icp_max_iter", C.c_int32), ("verbose", C.c_int32),
-                ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float)]
+                ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float),
+                ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
+                ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32)]
 
 
 class CCube(C.Structure):
@@ -65,6 +67,12 @@ SYMBOLS = {
     "goicp_cloud_load": (C.c_int, [C.c_char_p, C.c_float, C.c_float, C.c_uint64, C.POINTER(_fp), C.POINTER(C.c_size_t)]),
     "goicp_cloud_free": (None, [_fp]),
     "goicp_params_default": (None, [C.POINTER(CParams)]),
+    "goicp_params_from_config": (None, [C.POINTER(CConfig), C.POINTER(CParams)]),
+    "goicp_thresholds": (C.c_int, [_vp, _fp, C.POINTER(C.c_int32)]),
+    "goicp_device": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "goicp_set_progress_callback": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
+    "goicp_probe_gather": (C.c_int, [_vp, C.c_int32, C.c_size_t, C.POINTER(C.c_double)]),
+    "goicp_debug_kabsch": (C.c_int, [_fp, _fp]),
     "goicp_create": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.POINTER(_vp)]),
     "goicp_destroy": (C.c_int, [_vp]),
     "goicp_dt_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -44,7 +44,7 @@ int main(int argc, char** argv)
 		std::printf("mode %d: source %zu points, target %zu points, mse_threshold %g\n", config.mode, source.size(),
 		            target.size(), config.mse_threshold);
 		goicp_params p;
-		goicp_params_default(&p);
+		goicp_params_from_config(&config.raw, &p);      // mse_threshold + the [params.rotation] / [params.translation] search ranges
 		p.verbose = verbose;
 		p.trim_fraction = trim_fraction;
 		std::mutex mtx;

@@ -198,6 +198,10 @@ void load_config(const std::string& path, goicp_config* c)
 	}
 	c->rot_search_depth = (int)num_or(kv, "params.rotation.search_depth", 12);
 	c->trans_search_depth = (int)num_or(kv, "params.translation.search_depth", 12);
+	for (const auto& e : kv) {
+		if (e.first.rfind("params.rotation.", 0) == 0) c->has_rotation_range = 1;
+		if (e.first.rfind("params.translation.", 0) == 0) c->has_translation_range = 1;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1186,6 +1186,68 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 	*state = st;
 }
 
+// test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
+__global__ void kabsch_debug_kernel(const float* __restrict__ H, float* __restrict__ R)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	double Hd[9];
+	float Rf[9];
+	for (int i = 0; i < 9; i++) Hd[i] = (double)H[i];
+	kabsch_rotation_dev(Hd, Rf);
+	for (int i = 0; i < 9; i++) R[i] = Rf[i];
+}
+hipError_t launch_kabsch_debug(const float* d_H, float* d_R, hipStream_t stream)
+{
+	hipLaunchKernelGGL(kabsch_debug_kernel, dim3(1), dim3(64), 0, stream, d_H, d_R);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather-ceiling probe (bench.py roofline): the bounds kernel is bound by the vector-memory address /
+// L1 path, not by HBM, so its ceiling is measured, in the same run, by a kernel that does nothing
+// but issue independent 4-byte loads into the resident distance transform:
+//   MODE 0  fully coalesced: the 64 lanes of a wave-instruction read 64 consecutive floats (2 lines)
+//   MODE 1  fully divergent: the 64 lanes read 64 different 128-byte lines
+// Every workgroup draws its addresses from its own window of `window` floats (a power of two), so the
+// footprint per CU -- L1-resident, L2-resident, or the whole grid -- is the caller's choice.  Eight loads
+// in flight per lane per iteration, a wave-uniform LCG picks the bases (scalar ALU only).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_gather_kernel(const float* __restrict__ grid, unsigned n_floats, unsigned window, int iters,
+                                                           float* __restrict__ sink)
+{
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+	const unsigned span = n_floats - window;
+	const unsigned wbase = span ? (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % span) & ~63u : 0u;
+	const float* __restrict__ w = grid + wbase;
+	const unsigned mask = window - 1u;
+	unsigned h = __builtin_amdgcn_readfirstlane(wave * 2654435761u + 12345u);
+	float acc = 0.f;
+	const unsigned mine = MODE == 0 ? lane : lane * 32u;
+	for (int it = 0; it < iters; it++) {
+		float v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			h = h * 1664525u + 1013904223u;
+			const unsigned base = MODE == 0 ? ((h >> 7) & mask & ~63u) : ((h >> 7) & mask);
+			v[u] = w[(base + mine) & mask];
+		}
+#pragma unroll
+		for (int u = 0; u < 8; u++) acc += v[u];
+	}
+	if (acc == 1.2345e-30f) sink[0] = acc;      // never true for a distance field; keeps the loads alive
+}
+
+hipError_t launch_probe_gather(const DtDesc& dt, int mode, unsigned window, int blocks, int iters, float* sink, hipStream_t stream)
+{
+	const unsigned n = dt.layout ? (unsigned)dt.VB * dt.VB * dt.VB * 64u : (unsigned)dt.V * dt.V * dt.V;
+	if (window < 4096u || (window & (window - 1u)) || window > n) return hipErrorInvalidValue;
+	if (mode == 0) hipLaunchKernelGGL(probe_gather_kernel<0>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink);
+	else hipLaunchKernelGGL(probe_gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink);
+	return hipGetLastError();
+}
+
 int icp_blocks(int N)
 {
 	const int per_block = (kIcpThreads / 64) * 4;      // four queries per wavefront

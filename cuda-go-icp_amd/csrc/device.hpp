@@ -109,6 +109,11 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2,
                            hipStream_t stream);
 
+// ---- test / measurement helpers ---------------------------------------------------------------
+hipError_t launch_kabsch_debug(const float* d_H9, float* d_R9, hipStream_t stream);
+// window: floats per workgroup window (power of two >= 4096, <= grid size); 8*iters loads per lane
+hipError_t launch_probe_gather(const DtDesc& dt, int mode, unsigned window, int blocks, int iters, float* sink, hipStream_t stream);
+
 // ---- device-side build of the box hierarchy (kdbuild.hip): Morton sort + bottom-up boxes ----------
 hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], float ext, float* const boxes[kMaxLevels],
                            float4* pts, hipStream_t stream);

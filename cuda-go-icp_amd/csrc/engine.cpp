@@ -51,7 +51,41 @@ uint32_t part1by2(uint32_t x)
 	return x;
 }
 
+// device allocation that frees itself on every exit path (temporaries of init / operators)
+template <class T> struct DevBuf {
+	T* p = nullptr;
+	DevBuf() = default;
+	explicit DevBuf(size_t n) { HIPCHK(hipMalloc(&p, sizeof(T) * (n ? n : 1))); }
+	~DevBuf() { hipFree(p); }
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	T* release() { T* q = p; p = nullptr; return q; }
+};
+
 }  // namespace
+
+Engine::DeviceGuard::DeviceGuard(int dev) : want(dev)
+{
+	if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+	if (prev != want) HIPCHK(hipSetDevice(want));
+}
+Engine::DeviceGuard::~DeviceGuard()
+{
+	if (prev >= 0 && prev != want) hipSetDevice(prev);
+}
+
+void* Engine::scratch_bytes(size_t bytes)
+{
+	if (bytes > cap_opscratch_) {
+		HIPCHK(hipStreamSynchronize(stream_));
+		hipFree(d_opscratch_);
+		d_opscratch_ = nullptr; cap_opscratch_ = 0;
+		const size_t cap = std::max(bytes, (size_t)1 << 16);
+		HIPCHK(hipMalloc(&d_opscratch_, cap));
+		cap_opscratch_ = cap;
+	}
+	return d_opscratch_;
+}
 
 struct Engine::InnerSearch {
 	int rot_slot = 0;
@@ -99,7 +133,9 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		throw std::runtime_error("goicp: no HIP device available (this engine has no CPU fallback)");
-	if (p_.device >= 0) HIPCHK(hipSetDevice(p_.device));
+	if (p_.device >= ndev) throw std::invalid_argument("goicp: device ordinal out of range");
+	if (p_.device >= 0) dev_ = p_.device; else HIPCHK(hipGetDevice(&dev_));
+	DeviceGuard guard(dev_);
 	HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate(&ev0_));
 	HIPCHK(hipEventCreate(&ev1_));
@@ -111,9 +147,41 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	sse_thresh_ = p_.mse_threshold * (float)inliers_;         // jly_goicp.cpp:208
 	icp_err_diff_ = p_.mse_threshold / 10000;        // jly_goicp.cpp:186
 
-	// rotation uncertainty coefficients per level (jly_goicp.cpp:153-159)
+	// ---- search domain: the CPU path's roots (jly_goicp.cpp:44-53) unless the configured ranges narrow it ----
+	rot_root_ = Node{(float)-kPI, (float)-kPI, (float)-kPI, (float)(2 * kPI), 0.f, 0.f, 0};
+	trans_root_ = Node{-0.5f, -0.5f, -0.5f, 1.0f, 0.f, 0.f, 0};
+	auto cube_of_box = [](const float lo[3], const float hi[3], Node* root) {
+		float w = 0.f;
+		for (int k = 0; k < 3; k++) {
+			if (!(hi[k] >= lo[k]) || !std::isfinite(lo[k]) || !std::isfinite(hi[k])) throw std::invalid_argument("goicp: empty or non-finite search range");
+			w = std::max(w, hi[k] - lo[k]);
+		}
+		if (!(w > 0.f)) w = 1e-6f;          // a point range: one tiny cube
+		root->x = (lo[0] + hi[0]) / 2 - w / 2; root->y = (lo[1] + hi[1]) / 2 - w / 2; root->z = (lo[2] + hi[2]) / 2 - w / 2;
+		root->w = w;
+	};
+	if (p_.use_rot_range) {
+		bool full = true;
+		for (int k = 0; k < 3; k++) full = full && p_.rot_min[k] <= -180.f && p_.rot_max[k] >= 180.f;
+		if (!full) {
+			for (int k = 0; k < 3; k++) {
+				rot_lo_[k] = std::max((float)-kPI, (float)((double)p_.rot_min[k] * kPI / 180.0));
+				rot_hi_[k] = std::min((float)kPI, (float)((double)p_.rot_max[k] * kPI / 180.0));
+			}
+			cube_of_box(rot_lo_, rot_hi_, &rot_root_);
+			rot_boxed_ = true;
+		}
+	}
+	if (p_.use_trans_range) {
+		for (int k = 0; k < 3; k++) { trans_lo_[k] = p_.trans_min[k]; trans_hi_[k] = p_.trans_max[k]; }
+		cube_of_box(trans_lo_, trans_hi_, &trans_root_);
+		// a cubic range IS the root: nothing to cull
+		trans_boxed_ = !(trans_hi_[0] - trans_lo_[0] == trans_root_.w && trans_hi_[1] - trans_lo_[1] == trans_root_.w && trans_hi_[2] - trans_lo_[2] == trans_root_.w);
+	}
+
+	// rotation uncertainty coefficients per level (jly_goicp.cpp:153-159); level l = cubes of width root/2^l
 	for (int l = 0; l < kMaxRotLevel; l++) {
-		float w0 = (float)(2 * kPI);
+		float w0 = rot_root_.w;
 		float sigma = (float)((double)w0 / std::pow(2.0, l) / 2.0);
 		float maxAngle = (float)(kSQRT3 * (double)sigma);
 		if ((double)maxAngle > kPI) maxAngle = (float)kPI;
@@ -256,16 +324,16 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		double t0 = now_ms();
 		const size_t V = dt_.V, nlin = V * V * V;
 		const size_t nout = dt_.layout ? (size_t)dt_.VB * dt_.VB * dt_.VB * 64 : nlin;
-		float* d_model = nullptr;
-		int32_t* d_work = nullptr;
-		HIPCHK(hipMalloc(&d_model, sizeof(float) * 3 * M_));
+		DevBuf<float> model_buf(3 * M_);
+		DevBuf<int32_t> work_buf(nlin);
+		float* d_model = model_buf.p;
+		int32_t* d_work = work_buf.p;
 		HIPCHK(hipMemcpyAsync(d_model, target, sizeof(float) * 3 * M_, hipMemcpyHostToDevice, stream_));
-		HIPCHK(hipMalloc(&d_work, sizeof(int32_t) * nlin));
 		if (dt_.layout) {
 			HIPCHK(hipMalloc(&d_dt_, sizeof(float) * nout));
 			HIPCHK(hipMemsetAsync(d_dt_, 0, sizeof(float) * nout, stream_));
 		} else {
-			d_dt_ = reinterpret_cast<float*>(d_work);
+			d_dt_ = reinterpret_cast<float*>(work_buf.release());   // the linear grid is built in place: the engine owns it from here
 		}
 		dt_.grid = d_dt_;
 		{   // table of the out-of-grid extension term, same float sqrt + double divide as the kernel's fallback
@@ -279,8 +347,6 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		}
 		HIPCHK(launch_dt_build(d_model, (int)M_, dt_, d_work, d_dt_, stream_));
 		HIPCHK(hipStreamSynchronize(stream_));
-		HIPCHK(hipFree(d_model));
-		if (dt_.layout) HIPCHK(hipFree(d_work));
 		dt_build_ms_ = now_ms() - t0;
 	}
 	lap("distance transform");
@@ -304,8 +370,8 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			int K = 1;
 			while (K < kMaxLevels && (long long)kLeafSlots * (1LL << (6 * K)) < (long long)M_) K++;
 			if ((long long)kLeafSlots * (1LL << (6 * K)) < (long long)M_) throw std::invalid_argument("goicp: target cloud too large for the k-d tree");
-			float* d_model = nullptr;
-			HIPCHK(hipMalloc(&d_model, sizeof(float) * 3 * M_));
+			DevBuf<float> model_buf(3 * M_);
+			float* d_model = model_buf.p;
 			HIPCHK(hipMemcpyAsync(d_model, target, sizeof(float) * 3 * M_, hipMemcpyHostToDevice, stream_));
 			for (int l = 0; l < K; l++) HIPCHK(hipMalloc(&d_kd_boxes_[l], sizeof(float) * 384 * ((size_t)1 << (6 * l))));
 			HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kLeafSlots * ((size_t)1 << (6 * K))));
@@ -314,7 +380,6 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 				for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], target[3 * i + k]); mx[k] = std::max(mx[k], target[3 * i + k]); }
 			const float ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]});
 			HIPCHK(launch_kd_build(d_model, (int)M_, K, mn, ext, d_kd_boxes_, d_kd_pts_, stream_));
-			HIPCHK(hipFree(d_model));
 			kd_.K = K;
 		}
 		for (int l = 0; l < kMaxLevels; l++) kd_.boxes[l] = d_kd_boxes_[l];
@@ -342,7 +407,10 @@ Engine::~Engine() { release(); }
 
 void Engine::release()
 {
+	int prev = -1;
+	if (stream_ && hipGetDevice(&prev) == hipSuccess && prev != dev_) hipSetDevice(dev_); else prev = -1;
 	if (stream_) hipStreamSynchronize(stream_);
+	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_);
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
@@ -366,6 +434,7 @@ void Engine::release()
 	d_icp_partials_ = nullptr; d_icp_state_ = nullptr; h_icp_state_ = nullptr;
 	d_nn_d2_ = nullptr; d_nn_slot_ = nullptr; d_include_ = nullptr;
 	ev0_ = ev1_ = nullptr; stream_ = nullptr;
+	if (prev >= 0) hipSetDevice(prev);
 }
 
 void Engine::ensure_batch(size_t B, size_t K)
@@ -375,6 +444,7 @@ void Engine::ensure_batch(size_t B, size_t K)
 		hipStreamSynchronize(stream_);
 		hipFree(d_cubes_); hipFree(d_ub_); hipFree(d_lb_);
 		hipHostFree(h_cubes_); hipHostFree(h_ub_); hipHostFree(h_lb_);
+		d_cubes_ = nullptr; d_ub_ = d_lb_ = nullptr; h_cubes_ = nullptr; h_ub_ = h_lb_ = nullptr; cap_cubes_ = 0;   // a throwing hipMalloc must not leave freed pointers behind
 		HIPCHK(hipMalloc(&d_cubes_, sizeof(CubeRec) * cap));
 		HIPCHK(hipMalloc(&d_ub_, sizeof(float) * cap));
 		HIPCHK(hipMalloc(&d_lb_, sizeof(float) * cap));
@@ -387,6 +457,7 @@ void Engine::ensure_batch(size_t B, size_t K)
 		size_t cap = std::max<size_t>(K, cap_rots_ * 2);
 		hipStreamSynchronize(stream_);
 		hipFree(d_rots_); hipHostFree(h_rots_);
+		d_rots_ = nullptr; h_rots_ = nullptr; cap_rots_ = 0;
 		HIPCHK(hipMalloc(&d_rots_, sizeof(Rot9) * cap));
 		HIPCHK(hipHostMalloc(&h_rots_, sizeof(Rot9) * cap));
 		cap_rots_ = cap;
@@ -398,6 +469,7 @@ void Engine::ensure_batch(size_t B, size_t K)
 	if (need > cap_scratch_) {
 		hipStreamSynchronize(stream_);
 		hipFree(d_scratch_);
+		d_scratch_ = nullptr; cap_scratch_ = 0;
 		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
 		cap_scratch_ = need;
 	}
@@ -408,10 +480,14 @@ void Engine::ensure_batch(size_t B, size_t K)
 // ------------------------------------------------------------------------------------------------
 void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s, const ParentRec* d_parents)
 {
+	DeviceGuard guard(dev_);
 	size_t need = bounds_scratch_floats(B, (int)N_, nullptr, nullptr);
 	if (need > cap_scratch_) {
-		HIPCHK(hipDeviceSynchronize());
+		// only the two streams that can still be using the old scratch, not the whole device
+		HIPCHK(hipStreamSynchronize(stream_));
+		if (s && s != stream_) HIPCHK(hipStreamSynchronize(s));
 		hipFree(d_scratch_);
+		d_scratch_ = nullptr; cap_scratch_ = 0;
 		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
 		cap_scratch_ = need;
 	}
@@ -424,6 +500,7 @@ void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, 
 
 float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters)
 {
+	DeviceGuard guard(dev_);
 	eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_);   // sizes the scratch
 	HIPCHK(hipStreamSynchronize(stream_));
 	HIPCHK(hipEventRecord(ev0_, stream_));
@@ -438,6 +515,7 @@ float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B,
 void Engine::eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cubes, size_t B, float* ub, float* lb)
 {
 	if (B == 0) return;
+	DeviceGuard guard(dev_);
 	for (size_t i = 0; i < B; i++)
 		if (cubes[i].rot < 0 || (size_t)cubes[i].rot >= K) throw std::invalid_argument("goicp: cube rotation index out of range");
 	ensure_batch(B, K);
@@ -457,6 +535,7 @@ void Engine::eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cube
 void Engine::eval_bounds(const float R[9], const float* cubes4, size_t B, int level, float* ub, float* lb)
 {
 	if (B == 0) return;
+	DeviceGuard guard(dev_);
 	ensure_batch(B, 1);
 	const float coeff = rot_coeff(level);
 	for (size_t i = 0; i < B; i++) {
@@ -481,6 +560,7 @@ float Engine::eval_sse(const float R[9], const float t[3])
 
 void Engine::dt_download(float* out)
 {
+	DeviceGuard guard(dev_);
 	const size_t V = dt_.V;
 	if (!dt_.layout) {
 		HIPCHK(hipMemcpy(out, d_dt_, sizeof(float) * V * V * V, hipMemcpyDeviceToHost));
@@ -500,24 +580,25 @@ void Engine::dt_download(float* out)
 void Engine::nn_query(const float* q, size_t n, int32_t* idx, float* d2)
 {
 	if (n == 0) return;
-	float* dq = nullptr; int32_t* di = nullptr; float* dd = nullptr;
-	HIPCHK(hipMalloc(&dq, sizeof(float) * 3 * n));
-	HIPCHK(hipMalloc(&di, sizeof(int32_t) * n));
-	HIPCHK(hipMalloc(&dd, sizeof(float) * n));
+	DeviceGuard guard(dev_);
+	// one grow-only scratch block: queries | indices | distances
+	char* base = static_cast<char*>(scratch_bytes(sizeof(float) * 5 * n));
+	float* dq = reinterpret_cast<float*>(base);
+	int32_t* di = reinterpret_cast<int32_t*>(base + sizeof(float) * 3 * n);
+	float* dd = reinterpret_cast<float*>(base + sizeof(float) * 4 * n);
 	HIPCHK(hipMemcpyAsync(dq, q, sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream_));
 	HIPCHK(launch_nn_query(dq, (int)n, kd_, dt_, di, dd, stream_));
 	HIPCHK(hipMemcpyAsync(idx, di, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipMemcpyAsync(d2, dd, sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
-	hipFree(dq); hipFree(di); hipFree(dd);
 }
 
 void Engine::source_transformed(const float R[9], const float t[3], float* out)
 {
 	// rigid transform apply on the device (kernTransform, src/goicp_kernel.cu:16-22), then back to the
 	// caller's point order
-	float4* d_tmp = nullptr;
-	HIPCHK(hipMalloc(&d_tmp, sizeof(float4) * N_));
+	DeviceGuard guard(dev_);
+	float4* d_tmp = static_cast<float4*>(scratch_bytes(sizeof(float4) * N_));
 	HIPCHK(hipMemcpyAsync(d_tmp, d_src_, sizeof(float4) * N_, hipMemcpyDeviceToDevice, stream_));
 	Pose pose;
 	std::memcpy(pose.R, R, sizeof(pose.R));
@@ -526,7 +607,6 @@ void Engine::source_transformed(const float R[9], const float t[3], float* out)
 	std::vector<float> h(4 * N_);
 	HIPCHK(hipMemcpyAsync(h.data(), d_tmp, sizeof(float4) * N_, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
-	HIPCHK(hipFree(d_tmp));
 	for (size_t i = 0; i < N_; i++) {
 		float* o = out + 3 * (size_t)src_perm_[i];
 		o[0] = h[4 * i]; o[1] = h[4 * i + 1]; o[2] = h[4 * i + 2];
@@ -573,6 +653,7 @@ void Engine::icp_state_fetch()
 
 float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters_out)
 {
+	DeviceGuard guard(dev_);
 	icp_state_init(R, t, err_diff, 1, 0);
 	const int chunk = std::max(1, p_.icp_chunk);
 	int queued = 0;
@@ -595,6 +676,7 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 
 float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
 {
+	DeviceGuard guard(dev_);
 	icp_state_init(R, t, 0.f, 0, 1);   // frozen: every pass does the same work
 	icp_launch_one();
 	HIPCHK(hipStreamSynchronize(stream_));
@@ -607,8 +689,43 @@ float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
 	return ms / (float)std::max(iters, 1);
 }
 
+double Engine::probe_gather(int mode, size_t window_bytes)
+{
+	DeviceGuard guard(dev_);
+	unsigned window = 4096;
+	while ((size_t)window * 4 < window_bytes && window < (1u << 30)) window <<= 1;
+	const size_t nfl = dt_.layout ? (size_t)dt_.VB * dt_.VB * dt_.VB * 64 : (size_t)dt_.V * dt_.V * dt_.V;
+	while ((size_t)window > nfl) window >>= 1;
+	int cus = 256;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, dev_) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+	const int blocks = cus * 8, iters = 256;
+	float* sink = static_cast<float*>(scratch_bytes(64));
+	HIPCHK(launch_probe_gather(dt_, mode, window, blocks, iters, sink, stream_));   // warm-up
+	HIPCHK(hipStreamSynchronize(stream_));
+	const int reps = 5;
+	HIPCHK(hipEventRecord(ev0_, stream_));
+	for (int r = 0; r < reps; r++) HIPCHK(launch_probe_gather(dt_, mode, window, blocks, iters, sink, stream_));
+	HIPCHK(hipEventRecord(ev1_, stream_));
+	HIPCHK(hipEventSynchronize(ev1_));
+	float ms = 0.f;
+	HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+	const double lookups = (double)reps * blocks * 256.0 * iters * 8.0;
+	return lookups / ((double)ms * 1e-3);
+}
+
+void debug_kabsch(const float H[9], float R[9])
+{
+	DevBuf<float> buf(18);
+	HIPCHK(hipMemcpy(buf.p, H, sizeof(float) * 9, hipMemcpyHostToDevice));
+	HIPCHK(launch_kabsch_debug(buf.p, buf.p + 9, nullptr));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(R, buf.p + 9, sizeof(float) * 9, hipMemcpyDeviceToHost));
+}
+
 void Engine::icp_step()
 {
+	DeviceGuard guard(dev_);
 	// one iteration from the current step pose, fresh means, standard Kabsch (icp_kernel.cu:219-279)
 	icp_state_init(stepR_, stepT_, 0.f, 0, 0);
 	icp_launch_one();
@@ -648,6 +765,7 @@ void Engine::ensure_stage(int k, size_t B)
 // 8 children of every popped node in ONE launch, digest the bounds, repeat until every search stops.
 void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
 {
+	DeviceGuard guard(dev_);
 	const double t_begin = now_ms();
 	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
 	const int K = std::max(1, p_.trans_batch);
@@ -712,8 +830,10 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 					c.x = par.x + (j & 1) * c.w; c.y = par.y + (j >> 1 & 1) * c.w; c.z = par.z + (j >> 2 & 1) * c.w;
 					const float ub = st.h_ub[o], lb = st.h_ub[st.B + o];
 					s->cubes++;
+					if (trans_boxed_ && !in_box(c, trans_lo_, trans_hi_)) continue;   // outside the configured translation range
 					if (ub < s->best) { s->best = ub; s->best_node = c; s->improved = true; }   // :319-324
 					if (lb >= s->best) continue;                                                  // :327
+					if (p_.trans_search_depth > 0 && !(std::ldexp(c.w, p_.trans_search_depth) > trans_root_.w)) continue;   // depth limit reached: evaluated, not expanded
 					c.ub = ub; c.lb = lb;
 					s->pq.push(c);
 				}
@@ -733,13 +853,14 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 
 float Engine::inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c)
 {
+	DeviceGuard guard(dev_);
 	std::vector<Rot9> rots(1);
 	std::memcpy(rots[0].r, R, sizeof(float) * 9);
 	InnerSearch s;
 	s.rot_slot = 0;
 	s.coeff = rot_coeff(level);
 	s.best = incumbent;
-	s.pq.push(Node{-0.5f, -0.5f, -0.5f, 1.0f, 0.f, 0.f, 0});   // jly_goicp.cpp:50-53
+	s.pq.push(trans_root_);   // jly_goicp.cpp:50-53
 	std::vector<InnerSearch*> v{&s};
 	run_inner(v, rots);
 	if (best_node && s.improved) { best_node[0] = s.best_node.x; best_node[1] = s.best_node.y; best_node[2] = s.best_node.z; best_node[3] = s.best_node.w; }
@@ -753,14 +874,19 @@ float Engine::inner_bnb(const float R[9], int level, float incumbent, float best
 // ------------------------------------------------------------------------------------------------
 void Engine::publish(bool finished)
 {
-	std::lock_guard<std::mutex> lk(mtx_);
-	std::memcpy(snap_.optR, optR_, sizeof(optR_)); std::memcpy(snap_.optT, optT_, sizeof(optT_));
-	std::memcpy(snap_.curR, curR_, sizeof(curR_)); std::memcpy(snap_.curT, curT_, sizeof(curT_));
-	snap_.best_sse = opt_err_;
-	snap_.finished = finished ? 1 : 0;
-	snap_.counters = cnt_;
-	snap_.dt_build_ms = dt_build_ms_;
-	snap_.register_ms = register_ms_;
+	Result copy;
+	{
+		std::lock_guard<std::mutex> lk(mtx_);
+		std::memcpy(snap_.optR, optR_, sizeof(optR_)); std::memcpy(snap_.optT, optT_, sizeof(optT_));
+		std::memcpy(snap_.curR, curR_, sizeof(curR_)); std::memcpy(snap_.curT, curT_, sizeof(curT_));
+		snap_.best_sse = opt_err_;
+		snap_.finished = finished ? 1 : 0;
+		snap_.counters = cnt_;
+		snap_.dt_build_ms = dt_build_ms_;
+		snap_.register_ms = register_ms_;
+		copy = snap_;
+	}
+	if (progress_cb_) progress_cb_(copy);      // outside the lock: the callback may poll
 }
 
 Result Engine::poll()
@@ -788,6 +914,7 @@ float Engine::icp_from(float R[9], float t[3])
 
 void Engine::offer_global_best(float sse, const float R[9], const float t[3])
 {
+	DeviceGuard guard(dev_);
 	if (sse < opt_err_) {
 		adopt(sse, R, t);
 		// drop queued nodes that can no longer win (jly_goicp.cpp:533-543)
@@ -804,6 +931,7 @@ void Engine::offer_global_best(float sse, const float R[9], const float t[3])
 
 void Engine::register_begin()
 {
+	DeviceGuard guard(dev_);
 	cancel_.store(false);
 	early_exit_ = converged_ = false;
 	rot_ramp_ = 8;
@@ -823,7 +951,7 @@ void Engine::register_begin()
 	if (p_.verbose) std::fprintf(stderr, "[goicp] init error %.6g (after ICP)\n", opt_err_);
 	bnb_ms_ = 0;
 
-	Node root{(float)-kPI, (float)-kPI, (float)-kPI, (float)(2 * kPI), 0.f, 0.f, 0};   // jly_goicp.cpp:44-48
+	const Node root = rot_root_;   // jly_goicp.cpp:44-48 unless [params.rotation] narrows it
 	if (world_ <= 1) {
 		queue_.push(root);
 	} else {
@@ -836,6 +964,7 @@ void Engine::register_begin()
 			for (int b = 0; b < 8; b++, k++) {
 				Node c2 = c1; c2.w = c1.w / 2; c2.l = 2;
 				c2.x = c1.x + (b & 1) * c2.w; c2.y = c1.y + (b >> 1 & 1) * c2.w; c2.z = c1.z + (b >> 2 & 1) * c2.w;
+				if (rot_boxed_ && !in_box(c2, rot_lo_, rot_hi_)) continue;
 				if (k % world_ == rank_) queue_.push(c2);
 			}
 		}
@@ -856,6 +985,7 @@ void Engine::process_parents(const std::vector<Node>& parents)
 			float v1 = c.x + c.w / 2, v2 = c.y + c.w / 2, v3 = c.z + c.w / 2;
 			// pi-ball cull (:443): float sqrt, double subtraction and comparison
 			if ((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - kSQRT3 * (double)c.w / 2 > kPI) continue;
+			if (rot_boxed_ && !in_box(c, rot_lo_, rot_hi_)) continue;     // outside the configured rotation range
 			Child k;
 			k.node = c;
 			rodrigues(v1, v2, v3, k.R);
@@ -865,7 +995,7 @@ void Engine::process_parents(const std::vector<Node>& parents)
 	if (kids.empty()) return;
 	std::vector<Rot9> rots(kids.size());
 	for (size_t i = 0; i < kids.size(); i++) std::memcpy(rots[i].r, kids[i].R, sizeof(float) * 9);
-	const Node troot{-0.5f, -0.5f, -0.5f, 1.0f, 0.f, 0.f, 0};
+	const Node troot = trans_root_;
 
 	auto handle_ub = [&](Child& k, InnerSearch& s) -> bool {   // jly_goicp.cpp:495-544; returns true on early exit
 		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
@@ -893,6 +1023,7 @@ void Engine::process_parents(const std::vector<Node>& parents)
 	auto handle_lb = [&](Child& k, InnerSearch& s) {           // :551-562
 		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
 		if (s.best >= opt_err_) return;
+		if (p_.rot_search_depth > 0 && k.node.l >= p_.rot_search_depth) return;   // depth limit: evaluated, not expanded
 		k.node.lb = s.best;
 		queue_.push(k.node);
 	};
@@ -935,6 +1066,7 @@ void Engine::process_parents(const std::vector<Node>& parents)
 
 StepStatus Engine::register_step(int max_rot_pops)
 {
+	DeviceGuard guard(dev_);
 	int pops = 0;
 	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
 		// Rotation parents expanded together: ramps 8, 16, 32 ... rot_batch.  Easy registrations end in
@@ -975,6 +1107,7 @@ void Engine::register_end()
 
 void Engine::run()
 {
+	DeviceGuard guard(dev_);
 	double t0 = now_ms();
 	register_begin();
 	while (true) {

@@ -30,6 +30,13 @@ struct Params {
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
+	// Search domain ([params.rotation] / [params.translation] of the reference's configs, test/skull_goicp.toml:22-41;
+	// declared in src/common.h:157-169, never parsed there).  Unset = the CPU path's fixed domain
+	// (jly_goicp.cpp:44-53): rotation cube [-pi,pi]^3, translation cube [-0.5,0.5]^3, no depth limit.
+	int use_rot_range = 0, use_trans_range = 0;
+	float rot_min[3] = {-180.f, -180.f, -180.f}, rot_max[3] = {180.f, 180.f, 180.f};   // degrees, angle-axis components
+	float trans_min[3] = {-0.5f, -0.5f, -0.5f}, trans_max[3] = {0.5f, 0.5f, 0.5f};
+	int rot_search_depth = 0, trans_search_depth = 0;   // 0 = unlimited; d: nodes of depth d are evaluated, not expanded
 };
 
 struct Counters {
@@ -84,11 +91,16 @@ public:
 	float time_icp_pass(const float R[9], const float t[3], int iters);
 	void nn_query(const float* q_xyz, size_t n, int32_t* idx, float* d2);
 	void icp_step();   // one ICP iteration on the engine's current pose (ICP::kdTreeGPUStep)
+	// measured ceiling of the gather path (4-byte loads into the resident DT): lookups/s; mode 0 coalesced, 1 divergent
+	double probe_gather(int mode, size_t window_bytes);
 
 	// ---- registration ----
 	void run();                                  // FastGoICP::run / GoICP::Register
 	void cancel() { cancel_.store(true); }
 	Result poll();
+	// called on the registering thread after every published snapshot (the reference's worker writes
+	// FastGoICP::optR/optT/curR/curT itself, fgoicp.cpp:68-69,85-86)
+	void set_progress_callback(std::function<void(const Result&)> cb) { progress_cb_ = std::move(cb); }
 	// stepped form for multi-GPU sharding
 	void set_shard(int rank, int world) { rank_ = rank; world_ = world; }
 	void register_begin();
@@ -103,6 +115,7 @@ public:
 	size_t n_target() const { return M_; }
 	const float* target_xyz() const { return h_target_.data(); }
 	float sse_threshold() const { return sse_thresh_; }
+	int device() const { return dev_; }
 	int inliers() const { return inliers_; }
 	float rot_coeff(int level) const;
 	hipStream_t stream() const { return stream_; }
@@ -123,7 +136,25 @@ private:
 	void icp_state_init(const float R[9], const float t[3], float err_diff, int carry_means, int frozen);
 	void icp_state_fetch();
 
+	// HIP's current device is per host thread: every public entry point re-establishes the engine's device
+	struct DeviceGuard {
+		int prev = -1, want = -1;
+		explicit DeviceGuard(int dev);
+		~DeviceGuard();
+	};
+	bool in_box(const Node& c, const float lo[3], const float hi[3]) const
+	{
+		return c.x + c.w > lo[0] && c.x < hi[0] && c.y + c.w > lo[1] && c.y < hi[1] && c.z + c.w > lo[2] && c.z < hi[2];
+	}
+	void* scratch_bytes(size_t bytes);   // grow-only device scratch for the query / transform operators
+
 	Params p_;
+	int dev_ = 0;
+	Node rot_root_{}, trans_root_{};
+	bool rot_boxed_ = false, trans_boxed_ = false;
+	float rot_lo_[3], rot_hi_[3], trans_lo_[3], trans_hi_[3];
+	std::function<void(const Result&)> progress_cb_;
+	void* d_opscratch_ = nullptr; size_t cap_opscratch_ = 0;
 	size_t M_ = 0, N_ = 0;
 	float sse_thresh_ = 0.f, icp_err_diff_ = 0.f;
 	int inliers_ = 0;             // inlierNum = (int)(Nd * (1 - trimFraction)), jly_goicp.cpp:201
@@ -185,5 +216,6 @@ void build_kdtree(const float* xyz, int M, int leaf_max, KdHost* out);
 // fn(0..ntasks-1) on up to `threads` host threads (tasks claimed from a counter; the first exception is rethrown)
 void parallel_tasks(int threads, int ntasks, const std::function<void(int)>& fn);
 void rodrigues(float ax, float ay, float az, float R[9]);   // jly_goicp.cpp:449-467
+void debug_kabsch(const float H[9], float R[9]);            // the device SVD routine on the current device (tests)
 
 }  // namespace goicp

@@ -47,6 +47,15 @@ void fill_counters(goicp_counters* o, const goicp::Counters& c)
 	o->icp_runs = c.icp_runs; o->icp_iters = c.icp_iters; o->bounds_launches = c.bounds_launches;
 }
 
+void fill_result(goicp_result* out, const goicp::Result& r)
+{
+	std::memcpy(out->optR, r.optR, sizeof(r.optR)); std::memcpy(out->optT, r.optT, sizeof(r.optT));
+	std::memcpy(out->curR, r.curR, sizeof(r.curR)); std::memcpy(out->curT, r.curT, sizeof(r.curT));
+	out->best_sse = r.best_sse; out->finished = r.finished;
+	fill_counters(&out->counters, r.counters);
+	out->dt_build_ms = r.dt_build_ms; out->register_ms = r.register_ms;
+}
+
 }  // namespace
 
 extern "C" {
@@ -82,6 +91,30 @@ void goicp_params_default(goicp_params* p)
 	p->dt_size = d.dt_size; p->dt_expand = d.dt_expand; p->mse_threshold = d.mse_threshold; p->dt_layout = d.dt_layout;
 	p->device = d.device; p->trans_batch = d.trans_batch; p->wide_children = d.wide_children;
 	p->icp_max_iter = d.icp_max_iter; p->verbose = d.verbose; p->morton_sort = d.morton_sort; p->rot_batch = d.rot_batch; p->trim_fraction = d.trim_fraction; p->kd_gpu_build = d.kd_gpu_build;
+	p->use_rot_range = d.use_rot_range; p->use_trans_range = d.use_trans_range;
+	for (int k = 0; k < 3; k++) {
+		p->rot_min[k] = d.rot_min[k]; p->rot_max[k] = d.rot_max[k];
+		p->trans_min[k] = d.trans_min[k]; p->trans_max[k] = d.trans_max[k];
+	}
+	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
+}
+
+void goicp_params_from_config(const goicp_config* c, goicp_params* p)
+{
+	if (!p) return;
+	goicp_params_default(p);
+	if (!c) return;
+	p->mse_threshold = c->mse_threshold;
+	if (c->has_rotation_range) {
+		p->use_rot_range = 1;
+		for (int k = 0; k < 3; k++) { p->rot_min[k] = c->rot_min[k]; p->rot_max[k] = c->rot_max[k]; }
+		p->rot_search_depth = c->rot_search_depth;
+	}
+	if (c->has_translation_range) {
+		p->use_trans_range = 1;
+		for (int k = 0; k < 3; k++) { p->trans_min[k] = c->trans_min[k]; p->trans_max[k] = c->trans_max[k]; }
+		p->trans_search_depth = c->trans_search_depth;
+	}
 }
 
 int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_target, const float* source_xyz,
@@ -100,6 +133,12 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 			if (params->rot_batch > 0) p.rot_batch = params->rot_batch;
 			p.trim_fraction = params->trim_fraction;
 			p.kd_gpu_build = params->kd_gpu_build;
+			p.use_rot_range = params->use_rot_range; p.use_trans_range = params->use_trans_range;
+			for (int k = 0; k < 3; k++) {
+				p.rot_min[k] = params->rot_min[k]; p.rot_max[k] = params->rot_max[k];
+				p.trans_min[k] = params->trans_min[k]; p.trans_max[k] = params->trans_max[k];
+			}
+			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }
@@ -112,6 +151,45 @@ int goicp_destroy(goicp_handle h)
 {
 	if (!h) return GOICP_OK;
 	return guarded([&] { delete h->e; delete h; });
+}
+
+int goicp_thresholds(goicp_handle h, float* sse_threshold, int32_t* inliers)
+{
+	REQUIRE(h);
+	if (sse_threshold) *sse_threshold = h->e->sse_threshold();
+	if (inliers) *inliers = h->e->inliers();
+	return GOICP_OK;
+}
+
+int goicp_device(goicp_handle h, int32_t* ordinal)
+{
+	REQUIRE(h && ordinal);
+	*ordinal = h->e->device();
+	return GOICP_OK;
+}
+
+int goicp_set_progress_callback(goicp_handle h, goicp_progress_fn cb, void* user)
+{
+	REQUIRE(h);
+	if (!cb) { h->e->set_progress_callback(nullptr); return GOICP_OK; }
+	h->e->set_progress_callback([cb, user](const goicp::Result& r) {
+		goicp_result out;
+		fill_result(&out, r);
+		cb(&out, user);
+	});
+	return GOICP_OK;
+}
+
+int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s)
+{
+	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1));
+	return guarded([&] { *lookups_per_s = h->e->probe_gather(mode, window_bytes); });
+}
+
+int goicp_debug_kabsch(const float H[9], float R[9])
+{
+	REQUIRE(H && R);
+	return guarded([&] { goicp::debug_kabsch(H, R); });
 }
 
 int goicp_dt_info(goicp_handle h, int32_t* V, double* scale, double origin[3])
@@ -229,12 +307,7 @@ int goicp_poll(goicp_handle h, goicp_result* out)
 {
 	REQUIRE(h && out);
 	return guarded([&] {
-		goicp::Result r = h->e->poll();
-		std::memcpy(out->optR, r.optR, sizeof(r.optR)); std::memcpy(out->optT, r.optT, sizeof(r.optT));
-		std::memcpy(out->curR, r.curR, sizeof(r.curR)); std::memcpy(out->curT, r.curT, sizeof(r.curT));
-		out->best_sse = r.best_sse; out->finished = r.finished;
-		fill_counters(&out->counters, r.counters);
-		out->dt_build_ms = r.dt_build_ms; out->register_ms = r.register_ms;
+		fill_result(out, h->e->poll());
 	});
 }
 

@@ -82,6 +82,11 @@ hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], 
 	void* tmp = nullptr;
 	size_t tmp_bytes = 0;
 	hipError_t e;
+	// every exit path frees the temporaries
+	struct Cleanup {
+		unsigned*& a; unsigned*& b; int*& c; int*& d; void*& t;
+		~Cleanup() { hipFree(a); hipFree(b); hipFree(c); hipFree(d); hipFree(t); }
+	} cleanup{keys, keys2, vals, vals2, tmp};
 	if ((e = hipMalloc(&keys, sizeof(unsigned) * M)) != hipSuccess) return e;
 	if ((e = hipMalloc(&keys2, sizeof(unsigned) * M)) != hipSuccess) return e;
 	if ((e = hipMalloc(&vals, sizeof(int) * M)) != hipSuccess) return e;
@@ -96,8 +101,7 @@ hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], 
 		const int upper_children = 1 << (6 * (l + 1));
 		hipLaunchKernelGGL(kd_level_kernel, dim3((upper_children + 255) / 256), dim3(256), 0, stream, boxes[l + 1], boxes[l], upper_children);
 	}
-	e = hipStreamSynchronize(stream);
-	hipFree(keys); hipFree(keys2); hipFree(vals); hipFree(vals2); hipFree(tmp);
+	e = hipStreamSynchronize(stream);            // the temporaries are in use until here
 	return e != hipSuccess ? e : hipGetLastError();
 }
 

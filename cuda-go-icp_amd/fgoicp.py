@@ -52,6 +52,20 @@ class Config:
             setattr(self.rotation, ax + "min", c.rot_min[k]); setattr(self.rotation, ax + "max", c.rot_max[k])
             setattr(self.translation, ax + "min", c.trans_min[k]); setattr(self.translation, ax + "max", c.trans_max[k])
         self.rotation.search_depth, self.translation.search_depth = c.rot_search_depth, c.trans_search_depth
+        self.rotation.present, self.translation.present = bool(c.has_rotation_range), bool(c.has_translation_range)
+        self._c = c
+
+    def engine_params(self):
+        """Keyword arguments for Registration / FastGoICP carrying what the TOML holds for the engine: the search
+        ranges and depths when the [params.rotation] / [params.translation] tables are present."""
+        p = B.CParams()
+        B.load_library().goicp_params_from_config(C.byref(self._c), C.byref(p))
+        out = {}
+        if p.use_rot_range:
+            out.update(use_rot_range=1, rot_min=list(p.rot_min), rot_max=list(p.rot_max), rot_search_depth=p.rot_search_depth)
+        if p.use_trans_range:
+            out.update(use_trans_range=1, trans_min=list(p.trans_min), trans_max=list(p.trans_max), trans_search_depth=p.trans_search_depth)
+        return out
 
 
 def load_cloud(filepath, subsample=1.0, resize=1.0, seed=0):
@@ -121,12 +135,17 @@ class Registration:
         for k, v in params.items():
             if not hasattr(p, k):
                 raise TypeError("unknown engine parameter %r" % k)
+            if isinstance(getattr(p, k), C.Array):
+                v = type(getattr(p, k))(*[float(x) for x in v])
             setattr(p, k, v)
         self.params = p
         h = C.c_void_p()
         B.check(self._lib.goicp_create(C.byref(p), _fptr(self.pct), len(self.pct), _fptr(self.pcs), len(self.pcs), C.byref(h)))
         self.handle = h
         self.ns, self.nt = len(self.pcs), len(self.pct)
+        thr, inl = C.c_float(), C.c_int32()
+        B.check(self._lib.goicp_thresholds(h, C.byref(thr), C.byref(inl)))
+        self.sse_threshold, self.inliers = np.float32(thr.value), inl.value     # as the engine uses them (trimming included)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -239,7 +258,7 @@ class FastGoICP:
         self.registration = Registration(pct, pcs, mse_threshold, **params)
         self.mtx = mtx or threading.Lock()
         self.mse_threshold = float(mse_threshold)
-        self.sse_threshold = np.float32(mse_threshold) * np.float32(len(self.registration.pcs))
+        self.sse_threshold = self.registration.sse_threshold      # mse_threshold * inlierNum (jly_goicp.cpp:198-208), from the engine
 
     def run(self):
         B.check(self.registration._lib.goicp_register(self.registration.handle))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GOICP_ABI_VERSION 1
+#define GOICP_ABI_VERSION 2
 
 typedef enum goicp_status {
 	GOICP_OK = 0,
@@ -64,6 +64,8 @@ typedef struct goicp_config {
 	float trans_min[3], trans_max[3];
 	int32_t trans_search_depth;
 	char description[GOICP_PATH_MAX];
+	int32_t has_rotation_range;       /* the TOML carries a [params.rotation] table (test/skull_goicp.toml:22-30) */
+	int32_t has_translation_range;    /* ... a [params.translation] table (test/skull_goicp.toml:32-41) */
 } goicp_config;
 
 int goicp_config_load(const char* toml_path, goicp_config* out);
@@ -99,9 +101,23 @@ typedef struct goicp_params {
 	int32_t rot_batch;       /* most rotation nodes expanded per round when wide_children (default 64; rounds ramp 8, 16, 32 ...) */
 	int32_t kd_gpu_build;    /* k-d tree (box hierarchy) built on the device (Morton order, looser boxes): 1 yes, 0 or -1 host median splits (default) */
 	float trim_fraction;     /* GoICP::trimFraction (src/goicp/jly_goicp.h:116): fraction of the largest residuals ignored; reference 0 */
+	/* Search domain: the [params.rotation] / [params.translation] tables of the reference's configs
+	 * (test/skull_goicp.toml:22-41; declared in src/common.h:157-169 but never parsed or applied there).
+	 * use_* = 0 (default): the CPU path's fixed domain (src/goicp/jly_goicp.cpp:44-53), rotation cube [-pi,pi]^3 in
+	 * angle-axis space, translation cube [-0.5,0.5]^3, unlimited depth.  use_* = 1: the root cube is the smallest cube
+	 * that contains the box, children outside the box are never evaluated as candidates or expanded; a rotation range
+	 * of +-180 degrees on every axis is the reference root itself.  *_search_depth > 0: nodes at that depth are
+	 * evaluated but not split further (the guarantee is then limited to that resolution). */
+	int32_t use_rot_range, use_trans_range;
+	float rot_min[3], rot_max[3];       /* degrees; components of the angle-axis vector */
+	float trans_min[3], trans_max[3];   /* in cloud units after `resize` */
+	int32_t rot_search_depth, trans_search_depth;
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);
+/* defaults + what a parsed config carries for the engine: mse_threshold and, when the TOML has them, the search
+ * ranges and depths (main.cpp:33-42 reads mse_threshold the same way) */
+void goicp_params_from_config(const goicp_config* c, goicp_params* p);
 
 /* FastGoICP::FastGoICP(pct, pcs, mse_threshold, mtx) (src/fgoicp/fgoicp.hpp:14-28) + Registration ctor
  * (registration.hpp:66-80) + GoICP::BuildDT/Initialize (src/goicp/jly_goicp.cpp:75-90,134-209):
@@ -109,6 +125,12 @@ void goicp_params_default(goicp_params* p);
 int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_target,
                  const float* source_xyz, size_t n_source, goicp_handle* out);
 int goicp_destroy(goicp_handle h);
+/* SSEThresh = mse_threshold * inlierNum and inlierNum = (int)(N * (1 - trim_fraction))
+ * (src/goicp/jly_goicp.cpp:198-208; FastGoICP::sse_threshold, src/fgoicp/fgoicp.hpp:23) as the engine uses them */
+int goicp_thresholds(goicp_handle h, float* sse_threshold, int32_t* inliers);
+/* HIP device ordinal the engine lives on.  Every entry point makes it current for the calling thread
+ * (HIP's current device is per thread) and restores the caller's afterwards. */
+int goicp_device(goicp_handle h, int32_t* ordinal);
 
 /* DT3D geometry (src/goicp/jly_3ddt.h:100-111) and the grid itself ([z][y][x], V^3 floats) */
 int goicp_dt_info(goicp_handle h, int32_t* V, double* scale, double origin_xyz[3]);
@@ -189,6 +211,12 @@ typedef struct goicp_result {
 	double dt_build_ms, register_ms;
 } goicp_result;
 int goicp_poll(goicp_handle h, goicp_result* out);
+/* Progress callback: invoked on the registering thread after every published snapshot (new best pose, end of a
+ * rotation round, finish).  This is how the C++ shim keeps FastGoICP::{optR,optT,curR,curT,finished} current while
+ * run() is executing on a worker thread (the reference's worker writes those members itself,
+ * src/fgoicp/fgoicp.cpp:68-69,85-86).  cb = NULL clears it.  Not to be changed while goicp_register() runs. */
+typedef void (*goicp_progress_fn)(const goicp_result* snapshot, void* user);
+int goicp_set_progress_callback(goicp_handle h, goicp_progress_fn cb, void* user);
 /* the output.toml the reference's configs promise (test/bunny_goicp.toml:12) but never write */
 int goicp_result_write_toml(goicp_handle h, const char* path);
 /* the viz.ply the reference's configs promise (test/bunny_goicp.toml:13) but never write: binary
@@ -211,6 +239,16 @@ int goicp_register_begin(goicp_handle h);
 int goicp_register_step(goicp_handle h, int32_t max_rot_pops, goicp_step_status* out);
 int goicp_offer_best(goicp_handle h, float sse, const float R[9], const float t[3]);
 int goicp_register_end(goicp_handle h);
+
+/* ---- measurement / test helpers ----------------------------------------------------------------
+ * goicp_probe_gather: measured ceiling of the path that bounds the cube-bound kernel -- independent 4-byte loads
+ * into the engine's resident distance transform, nothing else.  mode 0: the 64 lanes of a wave-instruction read 64
+ * consecutive floats; mode 1: 64 different 128-byte lines.  window_bytes = footprint each workgroup draws its
+ * addresses from (rounded up to a power of two, at least 16 KiB, at most the grid).  Result: lookups per second.
+ * goicp_debug_kabsch: the device-side 3x3 SVD / Kabsch routine of the ICP update (Matrix::svd use in
+ * src/goicp/jly_icp3d.hpp:266-285) on a caller-supplied H (row-major), on the current device; test-only. */
+int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s);
+int goicp_debug_kabsch(const float H[9], float R[9]);
 
 #ifdef __cplusplus
 }

@@ -45,9 +45,27 @@ def skull_to_f32(dst):
     return len(c)
 
 
+def spanner_to_f32(dst_target, dst_source):
+    """test/spanner_goicp.toml (BASELINE configs[3]): target noisy_flipped_model_spanner.ply (150 000 points,
+    present), resize 0.02.  Its source model_spanner.ply is one of the blobs missing from the reference checkout
+    (.MISSING_LARGE_BLOBS:4); SURVEY 8d's substitute is rotated_model_spanner.ply (150 000 points, the model under a
+    random rotation, made by transform_target.py) -- same problem class, noise sigma 0.5 * 0.02 per axis.
+    Both go through OUR loader with the config's resize."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    pkg = load_pkg()
+    out = []
+    for name, dst in (("noisy_flipped_model_spanner.ply", dst_target), ("rotated_model_spanner.ply", dst_source)):
+        c = pkg.load_cloud(os.path.join(REF, "data", "artec3d", name), 1.0, 0.02)
+        np.ascontiguousarray(c, dtype="<f4").tofile(dst)
+        out.append(len(c))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--clouds-only", action="store_true", help="only (re)write the input-cloud blobs")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: fixtures can only be regenerated in the build container")
@@ -60,6 +78,9 @@ def main():
         n = txt_to_f32(h, src, os.path.join(OUT, name + ".f32"))
         print(name, n, "points")
     print("skull_scan", skull_to_f32(os.path.join(OUT, "skull_scan.f32")), "points")
+    print("spanner target/source", spanner_to_f32(os.path.join(OUT, "spanner_target.f32"), os.path.join(OUT, "spanner_source.f32")), "points")
+    if args.clouds_only:
+        return
     procs = [
         subprocess.Popen([h, "units", OUT, mb, db, "10"], stdout=subprocess.DEVNULL),
         subprocess.Popen([h, "trim", OUT, mb, db, "10", "0.1"], stdout=subprocess.DEVNULL),

@@ -16,7 +16,9 @@
 //   units  <outdir> <model.txt> <data.txt> <stride>
 //   cloud  <out.f32> <cloud.txt>
 //   trim   <outdir> <model.txt> <data.txt> <stride> <trim_fraction>
-//   bench  <model.f32> <data.f32> <seconds>      (bench.py's cpu_baseline leg: the reference's own InnerBnB, timed)
+//   bench  <model.f32> <data.f32> <seconds>      (bench.py's cpu_baseline leg: the reference's own InnerBnB, timed;
+//                                                 run from oracle/_ref/ref_harness_bench = Release-flag objects)
+//   count  <model.f32> <data.f32> <calls> <out.json>   (ref_harness_count only: exact cube-bound counts of that sequence)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -488,6 +490,68 @@ static std::vector<glm::vec3> load_f32(const char* path)
 	return out;
 }
 
+// Exact count of cube bounds: one cube bound = Nd calls of DT3D::Distance (jly_goicp.cpp:262-315), so the count binary
+// (oracle/Makefile: same objects, linked with --wrap on DT3D::Distance) counts the lookups.  The timed binary is
+// linked WITHOUT the wrapper: pure reference objects.
+#ifdef GOICP_COUNT_DISTANCE
+static long long g_distance_calls = 0;
+extern "C" float __real__ZN4DT3D8DistanceEddd(DT3D* self, double x, double y, double z);
+extern "C" float __wrap__ZN4DT3D8DistanceEddd(DT3D* self, double x, double y, double z)
+{
+	g_distance_calls++;
+	return __real__ZN4DT3D8DistanceEddd(self, x, y, z);
+}
+#endif
+
+// The seeded sequence of InnerBnB calls both modes replay: call k uses rotation k/2 (seeded, inside the pi-ball),
+// even k = upper-bound search (no rotation radii), odd k = lower-bound search with the radii of level 3 + (k/2 % 5),
+// each from the standard translation root with the incumbent of the "full" golden cases.
+struct BenchSeq {
+	GoICP& g;
+	TRANSNODE rootT;
+	float incumbent;
+	std::mt19937 rng{20241223u};
+	std::uniform_real_distribution<float> ua{-3.14159265f, 3.14159265f};
+	long long calls = 0;
+	explicit BenchSeq(GoICP& g_) : g(g_), rootT(g_.initNodeTrans), incumbent(35.0f * (float)g_.Nd / 3038.0f) {}
+	void next()
+	{
+		const int N = g.Nd;
+		if (calls % 2 == 0) {
+			float v[3];
+			do { v[0] = ua(rng); v[1] = ua(rng); v[2] = ua(rng); } while (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > 9.8696f);
+			float R[9];
+			rodrigues(v, R);
+			for (int i = 0; i < N; i++) {            // jly_goicp.cpp:470-476
+				POINT3D& p = g.pData[i];
+				g.pDataTemp[i].x = R[0] * p.x + R[1] * p.y + R[2] * p.z;
+				g.pDataTemp[i].y = R[3] * p.x + R[4] * p.y + R[5] * p.z;
+				g.pDataTemp[i].z = R[6] * p.x + R[7] * p.y + R[8] * p.z;
+			}
+		}
+		const int level = 3 + (int)(calls / 2 % 5);
+		g.initNodeTrans = rootT;
+		g.optError = incumbent;
+		TRANSNODE best; best.x = best.y = best.z = best.w = 0;
+		g.InnerBnB(calls % 2 ? g.maxRotDis[level] : NULL, &best);
+		calls++;
+	}
+};
+
+static void bench_setup(GoICP& g, std::vector<glm::vec3>& model, std::vector<glm::vec3>& data, double* dt_build_s)
+{
+	g.pModel = model.data(); g.Nm = (int)model.size();
+	g.pData = data.data();   g.Nd = (int)data.size();
+	const double t_dt = now_s();
+	g.BuildDT();
+	*dt_build_s = now_s() - t_dt;
+	g.Initialize();
+}
+
+// bench <model.f32> <data.f32> <seconds>: the reference's own GoICP::InnerBnB on the committed fixture clouds, timed for
+// about <seconds> of wall clock after the DT build.  Prints the number of completed calls and the reference's own
+// tNodeCount (pops, including each call's final non-expanding pop); the caller turns `calls` into the EXACT number of
+// cube bounds with tests/golden/ref_bench_counts.json (written by `count`), after checking that the pops agree.
 static int cmd_bench(int argc, char** argv)
 {
 	if (argc < 5) return 1;
@@ -496,46 +560,58 @@ static int cmd_bench(int argc, char** argv)
 	const double budget = atof(argv[4]);
 	mse_threshold = 1e-3f;
 	GoICP g(mse_threshold);
-	g.pModel = model.data(); g.Nm = (int)model.size();
-	g.pData = data.data();   g.Nd = (int)data.size();
-	const double t_dt = now_s();
-	g.BuildDT();
-	const double dt_build_s = now_s() - t_dt;
-	g.Initialize();
-	const int N = g.Nd;
-	const TRANSNODE rootT = g.initNodeTrans;
-	const float incumbent = 35.0f * (float)N / 3038.0f;          // as the "full" golden cases
-	std::mt19937 rng(20241223u);
-	std::uniform_real_distribution<float> ua(-3.14159265f, 3.14159265f);
-	long long calls = 0;
+	double dt_build_s = 0;
+	bench_setup(g, model, data, &dt_build_s);
+	BenchSeq seq(g);
 	const long long pops0 = tNodeCount;
 	const double t0 = now_s();
-	while (now_s() - t0 < budget) {
-		float v[3];
-		do { v[0] = ua(rng); v[1] = ua(rng); v[2] = ua(rng); } while (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > 9.8696f);
-		float R[9];
-		rodrigues(v, R);
-		for (int i = 0; i < N; i++) {            // jly_goicp.cpp:470-476
-			POINT3D& p = g.pData[i];
-			g.pDataTemp[i].x = R[0] * p.x + R[1] * p.y + R[2] * p.z;
-			g.pDataTemp[i].y = R[3] * p.x + R[4] * p.y + R[5] * p.z;
-			g.pDataTemp[i].z = R[6] * p.x + R[7] * p.y + R[8] * p.z;
-		}
-		const int level = 3 + (int)(calls / 2 % 5);
-		for (int pass = 0; pass < 2 && now_s() - t0 < budget; pass++) {
-			g.initNodeTrans = rootT;
-			g.optError = incumbent;
-			TRANSNODE best; best.x = best.y = best.z = best.w = 0;
-			g.InnerBnB(pass ? g.maxRotDis[level] : NULL, &best);
-			calls++;
-		}
-	}
+	while (now_s() - t0 < budget) seq.next();
 	const double sec = now_s() - t0;
 	const long long pops = tNodeCount - pops0;
-	printf("{\"kind\": \"reference\", \"Nd\": %d, \"Nm\": %d, \"dt_build_s\": %.3f, \"seconds\": %.3f, \"inner_bnb_calls\": %lld, "
-	       "\"trans_pops\": %lld, \"cube_bounds\": %lld, \"cube_bounds_per_s\": %.1f}\n",
-	       N, g.Nm, dt_build_s, sec, calls, pops, 8 * pops, 8.0 * (double)pops / sec);
+	printf("{\"kind\": \"reference\", \"Nd\": %d, \"Nm\": %d, \"dt_build_s\": %.3f, \"seconds\": %.6f, \"inner_bnb_calls\": %lld, "
+	       "\"trans_pops\": %lld, \"cube_bounds_upper\": %lld}\n",
+	       g.Nd, g.Nm, dt_build_s, sec, seq.calls, pops, 8 * pops);
 	return 0;
+}
+
+// count <model.f32> <data.f32> <calls> <out.json>: replay the first <calls> calls of the same sequence and write, per
+// prefix of calls, the reference's pops and the exact number of cube bounds (Distance calls / Nd).
+static int cmd_count(int argc, char** argv)
+{
+#ifndef GOICP_COUNT_DISTANCE
+	fprintf(stderr, "count: this binary was linked without the Distance wrapper (use ref_harness_count)\n");
+	return 1;
+#else
+	if (argc < 6) return 1;
+	auto model = load_f32(argv[2]);
+	auto data = load_f32(argv[3]);
+	const long long ncalls = atoll(argv[4]);
+	mse_threshold = 1e-3f;
+	GoICP g(mse_threshold);
+	double dt_build_s = 0;
+	bench_setup(g, model, data, &dt_build_s);
+	BenchSeq seq(g);
+	std::vector<long long> pops(1, 0), cubes(1, 0);
+	const long long pops0 = tNodeCount;
+	g_distance_calls = 0;
+	for (long long k = 0; k < ncalls; k++) {
+		seq.next();
+		if (g_distance_calls % g.Nd) { fprintf(stderr, "count: lookups not a multiple of Nd\n"); return 1; }
+		pops.push_back(tNodeCount - pops0);
+		cubes.push_back(g_distance_calls / g.Nd);
+	}
+	FILE* f = fopen(argv[5], "w");
+	if (!f) return 1;
+	fprintf(f, "{\"what\": \"reference InnerBnB bench sequence (oracle/ref_harness.cpp BenchSeq): after k calls, the reference's tNodeCount and the exact number of cube bounds = DT3D::Distance calls / Nd\",\n");
+	fprintf(f, "\"Nd\": %d, \"Nm\": %d, \"calls\": %lld,\n\"pops_prefix\": [", g.Nd, g.Nm, ncalls);
+	for (size_t i = 0; i < pops.size(); i++) fprintf(f, "%lld%s", pops[i], i + 1 < pops.size() ? "," : "");
+	fprintf(f, "],\n\"cube_bounds_prefix\": [");
+	for (size_t i = 0; i < cubes.size(); i++) fprintf(f, "%lld%s", cubes[i], i + 1 < cubes.size() ? "," : "");
+	fprintf(f, "]\n}\n");
+	fclose(f);
+	printf("%lld calls: %lld pops, %lld exact cube bounds (8 x pops = %lld)\n", ncalls, pops.back(), cubes.back(), 8 * pops.back());
+	return 0;
+#endif
 }
 
 int main(int argc, char** argv)
@@ -546,5 +622,6 @@ int main(int argc, char** argv)
 	if (!strcmp(argv[1], "cloud")) return cmd_cloud(argc, argv);
 	if (!strcmp(argv[1], "trim")) return cmd_trim(argc, argv);
 	if (!strcmp(argv[1], "bench")) return cmd_bench(argc, argv);
+	if (!strcmp(argv[1], "count")) return cmd_count(argc, argv);
 	return 1;
 }

@@ -668,3 +668,218 @@ def test_poll_and_cancel_while_running(pkg, bunny_model, bunny_data):
     th.join(timeout=30)
     assert not th.is_alive() and eng.finished
     assert eng.get_best_error() <= seen[-1]
+
+
+# ----------------------------------------------------------------------------------------------
+# round 2: point-by-point lookup, device SVD, the two remaining BASELINE configs, search ranges
+# ----------------------------------------------------------------------------------------------
+def test_dt_lookup_point_by_point(pkg, oracle_dt_bunny, bunny_model):
+    """SURVEY a-1, point by point: an engine whose source is the single point (0,0,0) makes
+    goicp_eval_bounds(I, cube centre q, w = 0, fix_rot) return Distance(q)^2 exactly, so the 4 096 reference
+    DT3D::Distance samples of tests/golden/dt_lookup.json (jly_3ddt.cpp:981-1026; 1 024 of them around index 0 /
+    V-1, out-of-grid and negative-overshoot cases included) reach the HIP lookup one by one.  The golden queries
+    are doubles; the engine takes floats, so: bit-equal to the oracle at the float-rounded query, and against the
+    reference's own values <= 0.35 voxel wherever the rounding did not move the query into a neighbouring voxel."""
+    g = golden("dt_lookup")
+    q64 = np.array(g["query"]).reshape(-1, 3)
+    qf = q64.astype(np.float32)
+    ref = np.array(g["distance"], dtype=np.float32)
+    vox = 1.0 / g["scale"]
+    for layout in (1, 0):
+        reg = pkg.Registration(bunny_model, np.zeros((1, 3), np.float32), 1e-3, dt_layout=layout)
+        cubes = np.concatenate([qf, np.zeros((len(qf), 1), np.float32)], 1)
+        ub, lb = reg.eval_bounds(np.eye(3), cubes, -1)
+        d = oracle_dt_bunny.distance(qf.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(ub, d * d), "HIP lookup differs from the oracle's DT3D::Distance restatement"
+        assert np.array_equal(lb, ub)                                    # w = 0: no translation radius
+        got = np.sqrt(ub.astype(np.float64))
+        same_voxel = np.all(np.floor((q64 - [g["xmin"], g["ymin"], g["zmin"]]) * g["scale"] + 0.5)
+                            == np.floor((qf.astype(np.float64) - [g["xmin"], g["ymin"], g["zmin"]]) * g["scale"] + 0.5), axis=1)
+        assert same_voxel.mean() > 0.99
+        assert np.all(got[same_voxel] <= ref[same_voxel] + 1e-6) and np.max(ref[same_voxel] - got[same_voxel]) <= 0.35 * vox
+        assert np.mean(np.abs(got[same_voxel] - ref[same_voxel]) <= 1e-6) > 0.999          # index math exact
+        assert np.max(np.abs(got - ref)) <= (np.sqrt(3) + 0.35) * vox                       # a neighbouring voxel at worst
+        reg.close()
+
+
+def test_device_svd_golden(pkg):
+    """SURVEY a-6: the device-side Kabsch / SVD routine (one-sided Jacobi in fp64, device.hip kabsch_rotation_dev)
+    fed the reference's own Matrix::svd cases (tests/golden/svd3x3.json: 32 H, half of them x1000 scale),
+    R_ = V diag(1,1,det(V U^T)) U^T as jly_icp3d.hpp:266-285.  1e-5 as SURVEY 8c-6."""
+    import ctypes as C
+    lib = pkg.load_library()
+    worst = 0.0
+    for c in golden("svd3x3")["cases"]:
+        H = np.array(c["H"], np.float32)
+        R = np.empty(9, np.float32)
+        pkg.binding.check(lib.goicp_debug_kabsch(H.ctypes.data_as(C.POINTER(C.c_float)), R.ctypes.data_as(C.POINTER(C.c_float))))
+        worst = max(worst, np.abs(R - np.array(c["R"], np.float32)).max())
+        assert abs(np.linalg.det(R.reshape(3, 3).astype(np.float64)) - 1) <= 1e-5
+    assert worst <= 1e-5, worst
+
+
+def _kabsch(src, dst):
+    ms, md = src.mean(0), dst.mean(0)
+    U, _, Vt = np.linalg.svd((src - ms).T @ (dst - md))
+    R = Vt.T @ np.diag([1, 1, np.linalg.det(Vt.T @ U.T)]) @ U.T
+    return R, md - R @ ms
+
+
+def test_spanner_noisy(pkg, oracle_mod):
+    """BASELINE configs[3], test/spanner_goicp.toml:10-20: target noisy_flipped_model_spanner.ply (150 000 points,
+    sigma 0.5 * resize 0.02 = 0.01 noise per axis), resize 0.02, mse_threshold 1e-4 -> SSEThresh 15.  The config's source
+    model_spanner.ply is missing from the reference checkout (.MISSING_LARGE_BLOBS:4); SURVEY 8d's substitute
+    rotated_model_spanner.ply (the model under a random rotation, 150 000 points) is used -- parity with the reference is
+    therefore UNPINNED for this case (its CPU run would also take days); the bar is the ground truth, which the two
+    files define through their point-by-point correspondence.  Checked: single engine below SSEThresh at the true pose;
+    2 and 4 sharded engines reach the same optimum (SURVEY 8e invariant); exact NN on this hierarchy; cube bounds
+    against the oracle on a 1/10 subsample."""
+    from cuda_go_icp_amd import sharded
+    target, source = cloud("spanner_target"), cloud("spanner_source")
+    assert target.shape == source.shape == (150000, 3)
+    Rgt, tgt = _kabsch(source.astype(np.float64), target.astype(np.float64))
+    eng = pkg.FastGoICP(target, source, 1e-4)
+    assert abs(float(eng.sse_threshold) - 15.0) < 1e-3
+    eng.run()
+    sse1 = float(eng.get_best_error())
+    assert eng.finished and sse1 < eng.sse_threshold
+    # the spanner is flat and elongated: a 180-degree flip about its long axis is a deep local minimum, far above the threshold
+    assert rot_angle(eng.optR, Rgt) <= 1e-2 and np.linalg.norm(eng.optT - tgt) <= 5e-3
+    c1 = eng.counters
+    assert c1.cubes > 0 and c1.icp_iters > 0
+    # NN exact vs brute force on this hierarchy (150 000 points: three box levels)
+    rng = np.random.default_rng(7)
+    q = np.concatenate([source[rng.choice(len(source), 1500, replace=False)] @ Rgt.T.astype(np.float32) + tgt.astype(np.float32),
+                        rng.uniform(-1.6, 1.6, (500, 3)).astype(np.float32)]).astype(np.float32)
+    idx, d2 = eng.registration.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    eng.registration.close()
+    # sharded: the rotation cubes dealt to 2 / 4 engines, min-exchange of the best error between steps
+    for world in (2, 4):
+        engines = [pkg.FastGoICP(target, source, 1e-4) for _ in range(world)]
+        sse, R, t, _ = sharded.run_local_ranks(engines, rot_pops_per_step=8)
+        assert sse < engines[0].sse_threshold and abs(sse - sse1) <= 0.05 * sse1
+        assert rot_angle(R, Rgt) <= 1e-2 and np.linalg.norm(t - tgt) <= 5e-3
+        for e in engines:
+            e.registration.close()
+    # cube bounds vs the oracle on every 10th source point (same DT: V = 300 over the noisy target)
+    sub = np.ascontiguousarray(source[::10])
+    reg = pkg.Registration(target, sub, 1e-4)
+    dt = oracle_mod.DistanceTransform(target, 300, 2.0)
+    assert np.array_equal(reg.dt_download(), dt.grid())
+    R = pkg.fgoicp.rodrigues([2.5, -0.8, 1.2])
+    prot = oracle_mod.rotate(R, sub)
+    _, rho = oracle_mod.rot_radii(sub)
+    cubes = _cubes(rng, 48)
+    for level in (-1, 4):
+        ub, lb = reg.eval_bounds(R, cubes, level)
+        for i, c in enumerate(cubes):
+            oub, olb = oracle_mod.cube_bound(dt, prot, rho[level] if level >= 0 else None, c[:3], c[3])
+            assert abs(ub[i] - oub) <= 1e-4 * max(oub, 1e-3) and abs(lb[i] - olb) <= 1e-4 * max(olb, 1e-3), (i, level)
+    reg.close()
+
+
+S2_MSE = 2.0e-5      # just above the measured floor of the true basin (see the docstring)
+
+
+def test_s2_fullsize(pkg, oracle_mod):
+    """BASELINE configs[4]: synthetic S2, N = M = 1 000 000, DT 512^3 (537 MB, HBM-resident), full SE(3) BnB.
+    The oracle would take days here, so: size-independent properties (additivity over a split of the cloud,
+    lb <= ub, monotone lb along a shrinking cube), exact NN on a sample against brute force, idempotent NN, and a
+    registration whose threshold sits just above the noise floor of the true basin, so that the initial ICP (from the
+    identity, 3 rad away from the truth) cannot satisfy it and the outer BnB has to run (>= 50 rotation nodes) before
+    the ground truth is recovered."""
+    from cuda_go_icp_amd import synth
+    target, source, Rgt, tgt = synth.make_pair(**{k: synth.S2[k] for k in ("seed", "M", "N")})
+    V = synth.S2["V"]
+    eng = pkg.FastGoICP(target, source, S2_MSE, dt_size=V)
+    reg = eng.registration
+    rng = np.random.default_rng(11)
+    cubes = _cubes(rng, 64)
+    R = pkg.fgoicp.rodrigues([0.4, -0.3, 0.8])
+    half_a = pkg.Registration(target, source[:500000], S2_MSE, dt_size=V)
+    half_b = pkg.Registration(target, source[500000:], S2_MSE, dt_size=V)
+    for level in (-1, 5):
+        u, l = reg.eval_bounds(R, cubes, level)
+        ua, la = half_a.eval_bounds(R, cubes, level)
+        ub_, lb_ = half_b.eval_bounds(R, cubes, level)
+        assert np.allclose(u, ua + ub_, rtol=2e-5) and np.allclose(l, la + lb_, rtol=2e-5, atol=1e-5)
+        assert np.all(l <= u)
+    half_a.close(); half_b.close()
+    centre = np.tile(np.array([[0.1, -0.05, 0.2]], np.float32), (6, 1))
+    ws = np.array([[1.0], [0.5], [0.25], [0.125], [0.0625], [0.03125]], np.float32)
+    _, lbs = reg.eval_bounds(R, np.concatenate([centre, ws], 1), -1)
+    assert np.all(np.diff(lbs) >= 0)
+    q = np.concatenate([source[:300], rng.uniform(-1.2, 1.2, (100, 3)).astype(np.float32)])
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    idx, d2 = reg.nn_query(target[:20000])
+    assert np.all(d2 == 0) and np.all(np.all(target[idx] == target[:20000], axis=1))
+    eng.run()
+    c = eng.counters
+    assert eng.finished and eng.get_best_error() < eng.sse_threshold
+    assert c.rot_pops >= 50, "the outer BnB did not run (%d rotation nodes)" % c.rot_pops
+    assert rot_angle(eng.optR, Rgt) <= 2e-3 and np.linalg.norm(eng.optT - tgt) <= 2e-3
+    reg.close()
+
+
+def test_search_ranges_applied(pkg, bunny_model, bunny_data10):
+    """[params.rotation] / [params.translation] / search_depth (test/skull_goicp.toml:22-41) reach the
+    engine.  (i) the full +-180 degree range and the CPU path's translation cube reproduce the default search node for
+    node; (ii) a rotation + translation box around the known optimum finds the same optimum with no more rotation
+    nodes; (iii) a box that excludes the optimum (ICP refinement off, which may leave any box) does not report it;
+    (iv) a depth limit bounds the number of nodes."""
+    g = golden("e2e_bunny10")
+    base = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], trans_batch=1, wide_children=0)
+    base.run()
+    full = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], trans_batch=1, wide_children=0,
+                         use_rot_range=1, rot_min=[-180] * 3, rot_max=[180] * 3,
+                         use_trans_range=1, trans_min=[-0.5] * 3, trans_max=[0.5] * 3)
+    full.run()
+    assert full.counters.rot_pops == base.counters.rot_pops and full.counters.trans_pops == base.counters.trans_pops
+    assert full.get_best_error() == base.get_best_error()
+    from scipy.spatial.transform import Rotation
+    rv = np.degrees(Rotation.from_matrix(np.array(g["R"]).reshape(3, 3)).as_rotvec())
+    t0 = np.array(g["t"])
+    box = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], use_rot_range=1, rot_min=list(rv - 25), rot_max=list(rv + 20),
+                        use_trans_range=1, trans_min=list(t0 - 0.2), trans_max=list(t0 + 0.25))
+    box.run()
+    assert box.get_best_error() <= 1.02 * g["sse"] and rot_angle(box.optR, np.array(g["R"])) <= 3e-2
+    assert 0 < box.counters.rot_pops <= base.counters.rot_pops
+    away = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], use_rot_range=1,
+                         rot_min=list(-rv - 15), rot_max=list(-rv + 15), icp_max_iter=0)
+    away.run()
+    assert rot_angle(away.optR, np.array(g["R"])) > 0.3 or away.get_best_error() > 1.5 * g["sse"]
+    shallow = pkg.FastGoICP(bunny_model, bunny_data10, 1e-6, use_rot_range=1, rot_min=[-180] * 3, rot_max=[180] * 3, rot_search_depth=2,
+                            use_trans_range=1, trans_min=[-0.5] * 3, trans_max=[0.5] * 3, trans_search_depth=3)
+    shallow.run()
+    assert shallow.finished and shallow.counters.rot_pops <= 1 + 8 + 64
+    for e in (base, full, box, away, shallow):
+        e.registration.close()
+
+
+def test_progress_callback_and_device(pkg, bunny_model, bunny_data10):
+    """goicp_set_progress_callback: snapshots arrive on the registering thread, monotone in best_sse, the last one
+    finished; goicp_device reports the ordinal every entry point re-establishes (engine created in one thread,
+    driven from another)."""
+    import ctypes as C
+    import threading
+    eng = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, device=0)
+    seen = []
+    CB = C.CFUNCTYPE(None, C.POINTER(pkg.binding.CResult), C.c_void_p)
+    cb = CB(lambda r, u: seen.append((float(r.contents.best_sse), int(r.contents.finished), threading.get_ident())))
+    lib = pkg.load_library()
+    pkg.binding.check(lib.goicp_set_progress_callback(eng.registration.handle, C.cast(cb, C.c_void_p), None))
+    dev = C.c_int32(-1)
+    pkg.binding.check(lib.goicp_device(eng.registration.handle, C.byref(dev)))
+    assert dev.value == 0
+    tid = []
+    th = threading.Thread(target=lambda: (tid.append(threading.get_ident()), eng.run()))
+    th.start(); th.join()
+    pkg.binding.check(lib.goicp_set_progress_callback(eng.registration.handle, None, None))
+    assert len(seen) >= 2 and seen[-1][1] == 1 and all(s[2] == tid[0] for s in seen)
+    assert all(b[0] <= a[0] for a, b in zip(seen, seen[1:]))
+    assert seen[-1][0] == float(eng.get_best_error())
+    eng.registration.close()

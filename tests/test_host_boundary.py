@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(pkg):
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in the header but not exported" % name
     assert declared == set(binding.SYMBOLS), (declared ^ set(binding.SYMBOLS))
-    assert lib.goicp_abi_version() == 1
+    assert lib.goicp_abi_version() == 2
 
 
 def test_struct_sizes_match_abi(pkg):
@@ -169,3 +169,59 @@ def test_rodrigues_host_helper_matches_oracle(pkg, oracle_mod):
     for v in rng.uniform(-3, 3, (50, 3)):
         assert np.array_equal(pkg.fgoicp.rodrigues(v), oracle_mod.rodrigues(v))
     assert np.array_equal(pkg.fgoicp.rodrigues([0, 0, 0]), np.eye(3, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+# C++ shim (include/goicp_mi355.hpp): the reference's call sites compile against it
+# ----------------------------------------------------------------------------------------------
+SHIM_TU = os.path.join(ROOT, "tests", "shim_callsites.cpp")
+REF_GLM = "/root/reference/external/include"
+
+
+def _syntax_only(extra):
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include")] + extra + [SHIM_TU],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_shim_compiles_without_glm():
+    """The shim's own layout-compatible Mat3 / Vec3 (column-major, m[col][row]) carry the same call shapes."""
+    _syntax_only([])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_GLM, "glm")), reason="the reference's vendored glm is only in the build container")
+def test_shim_compiles_against_reference_glm():
+    """SURVEY 8(b): the call shapes of src/main.cpp:94,150 (FastGoICP construction from std::vector<glm::vec3>, worker
+    thread on &FastGoICP::run), src/goicp_kernel.cu:161-177 (the viewer's locked read of optR/optT/curR/curT/finished/
+    get_best_error with glm::mat3 / glm::vec3 on the other side), src/icp_kernel.h:9-13 / src/goicp_kernel.h:6-10 (the
+    step API) and src/fgoicp/registration.hpp:96-97, icp3d.hpp:30-35 (the operators) compile against the shim with the
+    reference's own vendored glm."""
+    _syntax_only(["-DSHIM_WITH_GLM", "-I", REF_GLM])
+
+
+def test_shim_matrix_layout_roundtrip(tmp_path):
+    """to_rows / from_rows: glm-style column-major <-> the C ABI's row-major float[9] (host-only program)."""
+    import subprocess
+    src = tmp_path / "rt.cpp"
+    src.write_text('''#include "goicp_mi355.hpp"
+#include <cstdio>
+using namespace goicp_mi355;
+int main() {
+    float r[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9}, back[9];
+    Mat3 M = from_rows(r);
+    if (M[1][0] != 2.f || M[0][1] != 4.f || M[2][1] != 6.f) return 1;      // m[col][row]
+    to_rows(M, back);
+    for (int i = 0; i < 9; i++) if (back[i] != r[i]) return 2;
+    icp::RotNode n(0.f, 0.f, 0.f, 3.1415926536f / 8, 0.f, 0.f);
+    if (n.level() != 3) return 3;
+    std::puts("ok");
+    return 0;
+}''')
+    exe = tmp_path / "rt"
+    lib_dir = os.path.join(ROOT, "cuda-go-icp_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", lib_dir, "-lgoicp_mi355",
+                        "-Wl,-rpath," + lib_dir, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -1,0 +1,33 @@
+"""Exploration on the GPU box (not a test): spanner and S2 registrations at several thresholds."""
+import sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_pkg, cloud, rot_angle
+pkg = load_pkg(); pkg.load_library()
+which = sys.argv[1] if len(sys.argv) > 1 else "spanner"
+if which == "spanner":
+    target, source = cloud("spanner_target"), cloud("spanner_source")
+    s, t = source.astype(np.float64), target.astype(np.float64)
+    ms, mt = s.mean(0), t.mean(0)
+    U, _, Vt = np.linalg.svd((s - ms).T @ (t - mt))
+    Rgt = Vt.T @ np.diag([1, 1, np.linalg.det(Vt.T @ U.T)]) @ U.T
+    tgt = mt - Rgt @ ms
+    for mse in (1e-4,):
+        t0 = time.time(); eng = pkg.FastGoICP(target, source, mse, verbose=1); t1 = time.time()
+        print("sse at GT pose:", eng.registration.compute_sse_error(Rgt, tgt), "thr", eng.sse_threshold, flush=True)
+        eng.run(); t2 = time.time()
+        c = eng.counters
+        print("spanner mse %g: create %.2fs run %.3fs sse %.4f rot_err %.5f t_err %.5f rot_pops %d cubes %d icp %d launches %d" % (
+            mse, t1 - t0, t2 - t1, eng.get_best_error(), rot_angle(eng.optR, Rgt), np.linalg.norm(eng.optT - tgt), c.rot_pops, c.cubes, c.icp_iters, c.bounds_launches), flush=True)
+        eng.registration.close()
+else:
+    from cuda_go_icp_amd import synth
+    target, source, Rgt, tgt = synth.make_pair(**{k: synth.S2[k] for k in ("seed", "M", "N")})
+    for mse in [float(x) for x in sys.argv[2:]] or [1e-4, 3e-5, 2e-5, 1.5e-5]:
+        t0 = time.time(); eng = pkg.FastGoICP(target, source, mse, dt_size=512, verbose=1); t1 = time.time()
+        print("sse at GT pose:", eng.registration.compute_sse_error(Rgt, tgt), "thr", eng.sse_threshold, flush=True)
+        eng.run(); t2 = time.time()
+        c = eng.counters
+        print("S2 mse %g: create %.2fs run %.3fs sse %.4f rot_err %.5f t_err %.5f rot_pops %d cubes %d icp %d launches %d" % (
+            mse, t1 - t0, t2 - t1, eng.get_best_error(), rot_angle(eng.optR, Rgt), np.linalg.norm(eng.optT - tgt), c.rot_pops, c.cubes, c.icp_iters, c.bounds_launches), flush=True)
+        eng.registration.close()

@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--kd-gpu-build", type=int, default=-1, help="tuning only: target hierarchy built on the device 1 / host 0 / auto -1")
     ap.add_argument("--morton", type=int, default=2, help="tuning only: source order 0 input / 1 Morton / 2 k-d order")
     ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="profiling runs: skip the gather-ceiling probes and the generic-path leg")
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
                     help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded end-to-end registration when N > 1")
@@ -307,14 +308,14 @@ def main():
         # measured, in this run, by a probe kernel that only issues independent 4-byte loads into the same resident DT
         # (goicp_probe_gather): coalesced / fully divergent, from an L1-sized, an L2-sized and the whole-grid window.
         probe = {}
-        for name, mode, window in (("coalesced_l1", 0, 16 << 10), ("coalesced_l2", 0, 2 << 20), ("coalesced_dt", 0, 1 << 40),
+        for name, mode, window in () if args.no_probe else (("coalesced_l1", 0, 16 << 10), ("coalesced_l2", 0, 2 << 20), ("coalesced_dt", 0, 1 << 40),
                                    ("divergent_l1", 1, 16 << 10), ("divergent_l2", 1, 2 << 20), ("divergent_dt", 1, 1 << 40)):
             v = C.c_double()
             B.check(lib.goicp_probe_gather(h, mode, window, C.byref(v)))
             probe[name] = round(v.value / 1e9, 2)
         lookups = float(Bc) * N                                    # one DT lookup per (cube, point)
         glook = lookups / launch_s / 1e9
-        peak = probe["coalesced_l1"]
+        peak = probe.get("coalesced_l1", float("nan"))
         # algorithmic bytes: SURVEY 8(d)'s no-reuse model (16 N ub pass / 20 N lb pass) and the kernel as built
         # (a point's 16 B are loaded once per 8 sibling cubes = 2 N per cube bound, + 4 N of DT voxels)
         alg_bytes = (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N
@@ -336,7 +337,7 @@ def main():
                     "frac": round(glook / peak, 4),
                     "peak_source": "goicp_probe_gather in this run: independent coalesced 4-B loads from a 16 KiB window per workgroup of the resident DT",
                     "probe_Glookup_per_s": probe,
-                    "frac_of_divergent_l2_probe": round(glook / probe["divergent_l2"], 4),
+                    "frac_of_divergent_l2_probe": round(glook / probe.get("divergent_l2", float("nan")), 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "hbm": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "traffic_GBs": None if traffic is None else round(traffic / launch_s / 1e9, 1),
@@ -352,11 +353,11 @@ def main():
         if limiter:
             roofline["limiter"] = limiter
         # ---- the generic path: SURVEY 8(d)'s batch of unrelated cubes through the same entry point ----
-        g_rots, g_recs, g_nlb = make_generic_batch(pkg, reg, Bc, 8, seed=99)
+        g_rots, g_recs, g_nlb = make_generic_batch(pkg, reg, Bc if not args.no_probe else 8, 8, seed=99)
         gd_rots = torch.from_numpy(g_rots.reshape(-1)).to(dev)
         gd_cubes = torch.from_numpy(g_recs.view(np.uint8).reshape(-1)).to(dev)
         gms = C.c_float()
-        B.check(lib.goicp_time_bounds_device(h, gd_rots.data_ptr(), gd_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(gms)))
+        B.check(lib.goicp_time_bounds_device(h, gd_rots.data_ptr(), gd_cubes.data_ptr(), len(g_recs), d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(gms)))
         generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
                    "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
                    "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}

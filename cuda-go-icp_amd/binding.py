@@ -34,7 +34,8 @@ class CParams(C.Structure):
                 ("wide_children", C.c_int32), ("icp_max_iter", C.c_int32), ("verbose", C.c_int32),
                 ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float),
                 ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
-                ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32)]
+                ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32),
+                ("icp_fused", C.c_int32), ("device_queues", C.c_int32)]
 
 
 class CCube(C.Structure):
@@ -56,6 +57,34 @@ class CResult(C.Structure):
 class CStepStatus(C.Structure):
     _fields_ = [("finished", C.c_int32), ("early_exit", C.c_int32), ("best_sse", C.c_float),
                 ("frontier_lb", C.c_float), ("rot_pops", C.c_int64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)
+
+
+class CCommOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("allreduce_min_u64", ALLREDUCE_FN), ("bcast", BCAST_FN)]
+
+
+class CShardStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("steps", "exchanges", "broadcasts", "donations", "donated_cubes")] + [("best_sse", C.c_float)]
+
+
+_fpp = C.POINTER(C.c_float)
+ENG_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32)
+ENG_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(CStepStatus))
+ENG_POSE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fpp, _fpp, _fpp)
+ENG_OFFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_float, _fpp, _fpp)
+ENG_QSIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32))
+ENG_DONATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _fpp, C.POINTER(C.c_int32))
+ENG_RECEIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fpp, C.c_int32)
+ENG_END_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class CShardEngineOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("sse_threshold", C.c_float), ("begin", ENG_BEGIN_FN), ("step", ENG_STEP_FN), ("pose", ENG_POSE_FN),
+                ("offer", ENG_OFFER_FN), ("queue_size", ENG_QSIZE_FN), ("donate", ENG_DONATE_FN), ("receive", ENG_RECEIVE_FN), ("end", ENG_END_FN)]
 
 
 # every symbol include/goicp_mi355.h declares: name -> (restype, argtypes)
@@ -101,6 +130,15 @@ SYMBOLS = {
     "goicp_register_step": (C.c_int, [_vp, C.c_int32, C.POINTER(CStepStatus)]),
     "goicp_offer_best": (C.c_int, [_vp, C.c_float, _fp, _fp]),
     "goicp_register_end": (C.c_int, [_vp]),
+    "goicp_run_sharded": (C.c_int, [C.POINTER(CShardEngineOps), C.POINTER(CCommOps), C.c_int32, C.c_int32, C.POINTER(CShardStats)]),
+    "goicp_register_sharded": (C.c_int, [_vp, C.POINTER(CCommOps), C.c_int32, C.c_int32, C.POINTER(CShardStats)]),
+    "goicp_thread_comm_create": (C.c_int, [C.c_int32, C.POINTER(CCommOps)]),
+    "goicp_thread_comm_destroy": (C.c_int, [C.POINTER(CCommOps)]),
+    "goicp_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "goicp_rccl_comm_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CCommOps)]),
+    "goicp_rccl_comm_wrap": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CCommOps)]),
+    "goicp_rccl_comm_destroy": (C.c_int, [C.POINTER(CCommOps)]),
+    "goicp_register_multi_gpu": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(CShardStats)]),
 }
 
 

@@ -1,0 +1,367 @@
+// Device-resident translation queues of the inner branch-and-bound (GoICP::InnerBnB, src/goicp/jly_goicp.cpp:227-340).
+//
+// The reference pops ONE translation node per step from a host priority queue and evaluates its 8 children; the
+// round-1 driver popped up to 32 nodes per search per round on the host and paid, per round, an upload of the
+// expansion records, a download of the bounds, an event wait and the host-side heap work.  Here every active inner
+// search (up to 1 024 of them run in lock-step: 64 rotation parents x 8 children x {upper-, lower-bound pass}) keeps
+// its queue in HBM, and a round is two launches with no host involvement:
+//
+//   bnb_queue_kernel   one workgroup per search: DIGEST the bounds of the children evaluated in the previous round
+//                      (update the search's incumbent, jly_goicp.cpp:319-324; push the children that survive, :327-335),
+//                      then SELECT this round's expansions -- the up-to-K queued nodes with the smallest lower bounds
+//                      (ties: wider cube first, jly_goicp.h:64-71), subject to the stop rule best - lb >= SSEThresh
+//                      (:257) -- remove them from the queue and append their records to the round's expansion list.
+//   bounds_queue_kernel (device.hip) evaluates the 8 children of every listed expansion; the list length is read from
+//                      device memory, a fixed grid walks the work items.
+//
+// The host only queues rounds and, every few rounds, reads one word to learn whether any search is still active.
+// Selection = exact K smallest by a 3-digit radix select on a 32-bit key (lb with its five lowest mantissa bits
+// replaced by the node's depth: lb ascending to 2^-19 relative, then wider cube first); order of equal keys = queue
+// position, so a run is bit-reproducible.  Pruning uses the incumbent after ALL children of the round are known
+// (the reference updates it child by child): never prunes a node the reference would keep alive for a valid reason,
+// only more of them -- any expansion order of a best-first BnB keeps the bounds valid.
+#include <hip/hip_runtime.h>
+
+#include "device.hpp"
+
+namespace goicp {
+
+namespace {
+
+constexpr int kQThreads = 256;
+constexpr int kQPer = kQueueCap / kQThreads;      // keys per thread held in registers (32)
+static_assert(kQueueCap % kQThreads == 0 && kQPer == 32, "queue capacity is sized for 32 keys per thread");
+static_assert(kQueueMaxPop <= 32, "the selection bookkeeping handles at most 32 expansions per search and round");
+
+struct QShared {
+	unsigned hist[2048];
+	unsigned sel_prefix, sel_rem;
+	unsigned wave_tot[kQThreads / 64];
+	unsigned short cnt[kQPer][kQThreads / 64];     // per (j, wavefront) counts: ties, then selected
+	int sel_pos[kQueueMaxPop];
+	int hole_pos[kQueueMaxPop];
+	float red_ub[kQThreads / 64];
+	int red_idx[kQThreads / 64];
+	unsigned push_tot[kQThreads / 64];
+	int n_sel, n_holes, parent_off, bcast;
+};
+
+__device__ __forceinline__ int node_depth(float root_w, float w)      // w = root_w * 2^-depth exactly
+{
+	return (int)((__float_as_uint(root_w) >> 23) & 0xffu) - (int)((__float_as_uint(w) >> 23) & 0xffu);
+}
+__device__ __forceinline__ unsigned node_key(float lb, int depth)
+{
+	return (__float_as_uint(lb) & ~31u) | (unsigned)min(max(depth, 0), 31);
+}
+__device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, float z, float w)
+{
+	return x + w > qp.lo[0] && x < qp.hi[0] && y + w > qp.lo[1] && y < qp.hi[1] && z + w > qp.lo[2] && z < qp.hi[2];
+}
+
+}  // namespace
+
+// nodes of search s: q[s * kQueueCap ...]
+__global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
+                                                              const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
+                                                              const float* __restrict__ ubs, const float* __restrict__ lbs,
+                                                              QCtl* __restrict__ ctl, int parity)
+{
+	__shared__ QShared sh;
+	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	QSearch* __restrict__ S = searches + s;
+	QNode* __restrict__ Q = q + (size_t)s * kQueueCap;
+	if (s == 0 && tid < 8) {
+		if (tid == 0) ctl->n_groups[parity ^ 1] = 0;                  // the next round's counter (its last reader has finished)
+		ctl->work[parity][tid] = 0;                                   // this round's work counters of the bound evaluation
+	}
+	if (S->done) return;
+
+	float best = S->best;
+	int count = S->count;
+	const int n_prev = S->n_parents;
+	// ------------------------------------------------------------------------------------------------------------
+	// digest: the bounds of the children evaluated in the previous round (8 per expansion, <= 256 children)
+	// ------------------------------------------------------------------------------------------------------------
+	if (n_prev > 0) {
+		const int C = 8 * n_prev, off = S->parent_off;
+		const bool mine = tid < C;
+		float cx = 0.f, cy = 0.f, cz = 0.f, cw = 0.f, ub = INFINITY, lb = INFINITY;
+		bool valid = false;
+		if (mine) {
+			const ParentRec pr = prev_parents[off + (tid >> 3)];
+			const int c = tid & 7;
+			cw = pr.w / 2;                                            // jly_goicp.cpp:262-270
+			cx = pr.x + (float)(c & 1) * cw; cy = pr.y + (float)((c >> 1) & 1) * cw; cz = pr.z + (float)((c >> 2) & 1) * cw;
+			ub = ubs[(size_t)8 * off + tid]; lb = lbs[(size_t)8 * off + tid];
+			valid = !qp.boxed || in_box(qp, cx, cy, cz, cw);         // outside the configured translation range: not a candidate
+		}
+		// incumbent: min ub over the valid children, first index on ties (jly_goicp.cpp:319-324 visits them in order)
+		float mub = valid ? ub : INFINITY;
+		int midx = valid ? tid : INT_MAX;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float ou = __shfl_xor(mub, o, 64);
+			const int oi = __shfl_xor(midx, o, 64);
+			if (ou < mub || (ou == mub && oi < midx)) { mub = ou; midx = oi; }
+		}
+		if (lane == 0) { sh.red_ub[wave] = mub; sh.red_idx[wave] = midx; }
+		__syncthreads();
+		mub = sh.red_ub[0]; midx = sh.red_idx[0];
+#pragma unroll
+		for (int w2 = 1; w2 < kQThreads / 64; w2++)
+			if (sh.red_ub[w2] < mub || (sh.red_ub[w2] == mub && sh.red_idx[w2] < midx)) { mub = sh.red_ub[w2]; midx = sh.red_idx[w2]; }
+		const bool improved = mub < best;
+		if (improved) best = mub;
+		if (improved && tid == midx) { S->bx = cx; S->by = cy; S->bz = cz; S->bw = cw; S->improved = 1; }
+		// push the children that can still improve on the incumbent (:327-335), unless the depth limit says leaf
+		bool push = valid && lb < best;
+		if (push && qp.depth > 0 && node_depth(qp.root_w, cw) >= qp.depth) push = false;
+		const unsigned long long pb = __ballot(push);
+		if (lane == 0) sh.push_tot[wave] = (unsigned)__popcll(pb);
+		__syncthreads();
+		unsigned before = 0, total = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < kQThreads / 64; w2++) { if (w2 < wave) before += sh.push_tot[w2]; total += sh.push_tot[w2]; }
+		if (count + (int)total > kQueueCap) {
+			// does not fit: flag it; the host re-runs the whole batch through its own queues (nothing is lost)
+			if (tid == 0) { atomicExch(&ctl->overflow, 1); S->done = 1; S->n_parents = 0; }
+			return;
+		}
+		if (push) {
+			const int pos = count + (int)before + (int)__popcll(pb & ((1ull << lane) - 1ull));
+			Q[pos] = QNode{cx, cy, cz, cw, ub, lb};
+		}
+		count += (int)total;
+		if (tid == 0) { S->pops += n_prev; S->cubes += C; }
+		__syncthreads();                                                 // the pushed nodes are read back below
+	}
+
+	// ------------------------------------------------------------------------------------------------------------
+	// select: the K queued nodes with the smallest keys
+	// ------------------------------------------------------------------------------------------------------------
+	const int n = count, K = qp.K;
+	unsigned key[kQPer];
+	float lbv[kQPer];
+#pragma unroll
+	for (int j = 0; j < kQPer; j++) {
+		const int i = j * kQThreads + tid;
+		if (i < n) {
+			const QNode nd = Q[i];
+			lbv[j] = nd.lb;
+			key[j] = node_key(nd.lb, node_depth(qp.root_w, nd.w));
+		} else { lbv[j] = INFINITY; key[j] = 0xffffffffu; }
+	}
+	// smallest key and the stop rule on it (jly_goicp.cpp:257): nothing left that could close the gap -> done
+	unsigned kmin = 0xffffffffu;
+	float lbmin = INFINITY;
+#pragma unroll
+	for (int j = 0; j < kQPer; j++) if (key[j] < kmin) { kmin = key[j]; lbmin = lbv[j]; }
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const unsigned ok = __shfl_xor(kmin, o, 64);
+		const float ol = __shfl_xor(lbmin, o, 64);
+		if (ok < kmin) { kmin = ok; lbmin = ol; }
+	}
+	if (lane == 0) { sh.wave_tot[wave] = kmin; sh.red_ub[wave] = lbmin; }
+	__syncthreads();
+	kmin = sh.wave_tot[0]; lbmin = sh.red_ub[0];
+#pragma unroll
+	for (int w2 = 1; w2 < kQThreads / 64; w2++) if (sh.wave_tot[w2] < kmin) { kmin = sh.wave_tot[w2]; lbmin = sh.red_ub[w2]; }
+	__syncthreads();
+	if (n == 0 || best - lbmin < qp.thr) {
+		if (tid == 0) {
+			S->best = best; S->count = n; S->n_parents = 0; S->done = 1;
+			if (n > 0) S->pops += 1;                                      // the reference counts the node it pops and rejects
+		}
+		return;
+	}
+
+	unsigned T = 0xffffffffu, rem = 0;                                  // selected: key < T, plus the first `rem` keys == T
+	if (n > K) {
+		if (tid == 0) { sh.sel_prefix = 0u; sh.sel_rem = (unsigned)K; }
+#pragma unroll 1
+		for (int pass = 0; pass < 3; pass++) {
+			const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0), width = pass == 2 ? 10 : 11, bins = 1 << width;
+			for (int i = tid; i < 2048; i += kQThreads) sh.hist[i] = 0u;
+			__syncthreads();
+			const unsigned prefix = sh.sel_prefix;
+#pragma unroll
+			for (int j = 0; j < kQPer; j++) {
+				const bool live = j * kQThreads + tid < n && (pass == 0 || (key[j] >> (shift + width)) == prefix);
+				if (live) atomicAdd(&sh.hist[(key[j] >> shift) & (unsigned)(bins - 1)], 1u);
+			}
+			__syncthreads();
+			// the bin holding the rem-th smallest candidate: eight bins per thread, wavefront scan, wavefront totals
+			unsigned h[8], local = 0;
+#pragma unroll
+			for (int b = 0; b < 8; b++) { h[b] = sh.hist[8 * tid + b]; local += h[b]; }
+			unsigned incl = local;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned v = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += v;
+			}
+			if (lane == 63) sh.wave_tot[wave] = incl;
+			__syncthreads();
+			unsigned before = 0;
+			for (int w2 = 0; w2 < wave; w2++) before += sh.wave_tot[w2];
+			const unsigned excl = before + incl - local, want = sh.sel_rem;
+			__syncthreads();                                              // every thread has read sel_rem before one rewrites it
+			if (excl < want && want <= excl + local) {                        // exactly one thread
+				unsigned cum = excl;
+#pragma unroll
+				for (int b = 0; b < 8; b++) {
+					if (cum < want && want <= cum + h[b]) {
+						sh.sel_prefix = (prefix << width) | (unsigned)(8 * tid + b);
+						sh.sel_rem = want - cum;
+					}
+					cum += h[b];
+				}
+			}
+			__syncthreads();
+		}
+		T = sh.sel_prefix; rem = sh.sel_rem;
+	}
+	// selected flags; the ties (key == T) are taken in queue order.  Per (j, wavefront) tie counts, then ranks.
+	unsigned tie_before[1] = {0};
+	bool sel[kQPer];
+	if (n > K) {
+#pragma unroll
+		for (int j = 0; j < kQPer; j++) {
+			const unsigned long long tb = __ballot(key[j] == T);
+			if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(tb);
+		}
+		__syncthreads();
+		unsigned wbefore = 0, total = 0;
+		if (lane < kQPer)
+			for (int w2 = 0; w2 < kQThreads / 64; w2++) {
+				const unsigned c = sh.cnt[lane][w2];
+				total += c;
+				wbefore += w2 < wave ? c : 0u;
+			}
+		unsigned incl = total;
+#pragma unroll
+		for (int o = 1; o < kQPer; o <<= 1) {
+			const unsigned v = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += v;
+		}
+		const unsigned base = incl - total + wbefore;                    // lane j: ties before (iteration j, this wavefront)
+#pragma unroll
+		for (int j = 0; j < kQPer; j++) {
+			const bool tie = key[j] == T;
+			const unsigned long long tb = __ballot(tie);
+			const unsigned rank = (unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
+			sel[j] = key[j] < T || (tie && rank < rem);
+		}
+		__syncthreads();
+	} else {
+#pragma unroll
+		for (int j = 0; j < kQPer; j++) sel[j] = j * kQThreads + tid < n;
+	}
+	(void)tie_before;
+	// the stop rule per node (:257): a selected node that can no longer close the gap stays queued
+#pragma unroll
+	for (int j = 0; j < kQPer; j++) sel[j] = sel[j] && !(best - lbv[j] < qp.thr);
+
+	// rank of every selected node in queue order -> slot in this round's expansion list
+#pragma unroll
+	for (int j = 0; j < kQPer; j++) {
+		const unsigned long long sb = __ballot(sel[j]);
+		if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(sb);
+	}
+	__syncthreads();
+	{
+		unsigned wbefore = 0, total = 0;
+		if (lane < kQPer)
+			for (int w2 = 0; w2 < kQThreads / 64; w2++) {
+				const unsigned c = sh.cnt[lane][w2];
+				total += c;
+				wbefore += w2 < wave ? c : 0u;
+			}
+		unsigned incl = total;
+#pragma unroll
+		for (int o = 1; o < kQPer; o <<= 1) {
+			const unsigned v = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += v;
+		}
+		const unsigned base = incl - total + wbefore;
+		if (tid == kQPer - 1) sh.n_sel = (int)incl;                       // wavefront 0, lane 31: total over all (j, wavefront)
+#pragma unroll
+		for (int j = 0; j < kQPer; j++) {
+			const unsigned long long sb = __ballot(sel[j]);
+			if (sel[j]) {
+				const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(sb & ((1ull << lane) - 1ull));
+				sh.sel_pos[r] = j * kQThreads + tid;
+			}
+		}
+	}
+	__syncthreads();
+	const int n_sel = sh.n_sel;
+	if (n_sel == 0) {
+		// only possible when nodes share the smallest (truncated) key and the first of them in queue order misses the
+		// stop rule by a rounding: the gap is closed to within 2^-19 relative -> done
+		if (tid == 0) { S->best = best; S->count = n; S->n_parents = 0; S->done = 1; S->pops += 1; }
+		return;
+	}
+	if (tid == 0) sh.parent_off = atomicAdd(&ctl->n_groups[parity], n_sel);
+	__syncthreads();
+	const int off = sh.parent_off;
+	const float coeff = S->coeff;
+	const int rot = S->rot;
+	if (tid < n_sel) {
+		const QNode nd = Q[sh.sel_pos[tid]];
+		parents[off + tid] = ParentRec{nd.x, nd.y, nd.z, nd.w, coeff, rot};
+	}
+	__syncthreads();
+	// remove the selected nodes: the holes among the first m = n - n_sel positions are filled, in order, with the
+	// unselected nodes of the tail [m, n)  (at most n_sel of each; one wavefront does it)
+	const int m = n - n_sel;
+	if (wave == 0) {
+		const bool is_hole = lane < n_sel && sh.sel_pos[lane] < m;
+		const unsigned long long hb = __ballot(is_hole);
+		if (is_hole) sh.hole_pos[__popcll(hb & ((1ull << lane) - 1ull))] = sh.sel_pos[lane];
+		const int tailpos = m + lane;
+		bool filler = lane < n_sel && tailpos < n;
+		if (filler)
+			for (int r = 0; r < n_sel; r++) if (sh.sel_pos[r] == tailpos) filler = false;
+		const unsigned long long fb = __ballot(filler);
+		QNode moved{};
+		if (filler) moved = Q[tailpos];
+		__builtin_amdgcn_wave_barrier();
+		if (filler) Q[sh.hole_pos[__popcll(fb & ((1ull << lane) - 1ull))]] = moved;
+	}
+	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; }
+}
+
+__global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, int nsearch, QParams qp, QCtl* __restrict__ ctl)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s == 0) {
+		ctl->n_groups[0] = 0; ctl->n_groups[1] = 0; ctl->overflow = 0;
+		for (int k = 0; k < 8; k++) { ctl->work[0][k] = 0; ctl->work[1][k] = 0; }
+	}
+	if (s >= nsearch) return;
+	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241
+	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
+	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
+	S.bx = S.by = S.bz = S.bw = 0.f;
+}
+
+hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream)
+{
+	if (nsearch <= 0) return hipSuccess;
+	hipLaunchKernelGGL(bnb_init_kernel, dim3((nsearch + 255) / 256), dim3(256), 0, stream, searches, q, nsearch, qp, ctl);
+	return hipGetLastError();
+}
+
+hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
+                            const float* ubs, const float* lbs, QCtl* ctl, int parity, hipStream_t stream)
+{
+	if (nsearch <= 0) return hipSuccess;
+	if (qp.K < 1 || qp.K > kQueueMaxPop) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, qp, prev_parents, parents, ubs, lbs, ctl, parity);
+	return hipGetLastError();
+}
+
+}  // namespace goicp

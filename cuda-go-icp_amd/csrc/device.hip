@@ -212,11 +212,12 @@ __device__ __forceinline__ bool is_sibling_set(const CubeRec cr[kGroup])
 // of one BnB expansion: same rotation, neighbouring translations -> neighbouring DT voxels) and a
 // contiguous chunk of the (k-d-ordered) source cloud; each point is loaded once (16 B) and
 // reused for the 8 cubes.
+// work item `work` of `total` = groups*chunks: one (cube group, point chunk) pair
 template <int LAYOUT>
-__global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
-    const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
+__device__ __forceinline__ void bounds_work(
+    int work, int total, const float4* __restrict__ src, int N, const DtDesc& dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
-    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
+    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, float (*red)[2 * kGroup])
 {
 	// XCD-aware tiling (speed only): blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns
 	// the point chunks [x*cpx, (x+1)*cpx) -- a compact spatial patch of the k-d-ordered cloud -- and
@@ -224,11 +225,11 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 	// of ONE patch under nearby translations (a few MB) instead of the whole surface band.
 	int chunk, group;
 	if ((chunks & 7) == 0) {
-		const int cpx = chunks >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+		const int cpx = chunks >> 3, xcd = work & 7, slot = work >> 3;
 		group = slot / cpx;
 		chunk = xcd * cpx + (slot - group * cpx);
 	} else {
-		const int swz = xcd_remap(blockIdx.x, gridDim.x);
+		const int swz = xcd_remap(work, total);
 		chunk = swz / groups; group = swz - chunk * groups;
 	}
 	const int c0 = group * kGroup;
@@ -294,7 +295,6 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 	}
 
 	// wave64 reduce, then 4 waves through LDS
-	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
 	for (int c = 0; c < kGroup; c++) {
@@ -312,6 +312,71 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
 		} else {
 			scratch[((size_t)group * chunks + chunk) * (2 * kGroup) + threadIdx.x] = s;
 		}
+	}
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
+    const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
+    const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
+    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
+{
+	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
+	bounds_work<LAYOUT>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red);
+}
+
+// The same evaluation for a batch whose size only the DEVICE knows (the device-resident BnB queues, bnbqueue.hip):
+// *d_groups expansions of 8 children each; a fixed grid walks the (group, chunk) work items, the split of the cloud
+// into chunks follows from the count exactly as on the host (bounds_shape).  ub_out / lb_out: [8 * groups] each.
+__host__ __device__ inline void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts);
+// Work distribution: a launch of exactly-sized grids lets the hardware hand the next block to whichever CU frees up;
+// a fixed grid that strides statically over the items loses that (measured on the full bunny: 22.2 ms of bound
+// evaluation against 15 ms -- item counts like 3.2 per block leave a quarter of the chip idle in the last pass).
+// So the fixed grid draws its items dynamically: eight counters, one per XCD slot (blocks b and b+8 share an XCD), each
+// handing out the items whose index is congruent to that slot -- the XCD-aware tiling of bounds_work is kept, and the
+// fetch of the next item overlaps the evaluation of the current one.
+template <int LAYOUT>
+__global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
+    const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots, const ParentRec* __restrict__ parents,
+    const int* __restrict__ d_groups, int* __restrict__ work8, float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
+{
+	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
+	__shared__ int next_item[2];
+	const int ngroups = *d_groups;
+	if (ngroups <= 0) return;
+	int groups, chunks, chunk_pts;
+	bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
+	const int total = groups * chunks;
+	const bool per_xcd = (total & 7) == 0;
+	const int slot = per_xcd ? (int)(blockIdx.x & 7) : 0, stride = per_xcd ? 8 : 1;
+	int* ctr = work8 + slot;
+	if (threadIdx.x == 0) next_item[0] = atomicAdd(ctr, 1);
+	__syncthreads();
+	int item = next_item[0], buf = 0;
+	while (item * stride + slot < total) {
+		if (threadIdx.x == 0) next_item[buf ^ 1] = atomicAdd(ctr, 1);   // in flight while this item is evaluated
+		bounds_work<LAYOUT>(item * stride + slot, total, src, N, dt, rots, nullptr, parents, ngroups * kGroup, groups, chunks, chunk_pts, scratch, ub_out,
+		                    lb_out, red);
+		__syncthreads();                                                 // `red` is reused by the next item; next_item is published
+		buf ^= 1;
+		item = next_item[buf];
+	}
+}
+
+__global__ void bounds_queue_finalize(const float* __restrict__ scratch, const int* __restrict__ d_groups, int N,
+                                      float* __restrict__ ub_out, float* __restrict__ lb_out)
+{
+	const int ngroups = *d_groups;
+	if (ngroups <= 0) return;
+	int groups, chunks, chunk_pts;
+	bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
+	if (chunks == 1) return;                                             // written directly by the evaluation kernel
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < groups * 2 * kGroup; t += gridDim.x * blockDim.x) {
+		const int group = t / (2 * kGroup), k = t - group * 2 * kGroup;
+		const float* s = scratch + (size_t)group * chunks * (2 * kGroup) + k;
+		float acc = 0.f;
+		for (int j = 0; j < chunks; j++) acc += s[(size_t)j * 2 * kGroup];
+		(k < kGroup ? ub_out : lb_out)[group * kGroup + (k & (kGroup - 1))] = acc;
 	}
 }
 
@@ -344,8 +409,12 @@ template <int LAYOUT>
 __global__ __launch_bounds__(kTrimThreads) void bounds_trim_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int inliers,
-    float* __restrict__ ub_out, float* __restrict__ lb_out)
+    float* __restrict__ ub_out, float* __restrict__ lb_out, const int* __restrict__ d_groups)
 {
+	if (d_groups) {                           // batch size known to the device only (device-resident BnB queues)
+		if ((int)blockIdx.x >= *d_groups) return;
+		B = *d_groups * kGroup;
+	}
 	__shared__ unsigned hist[kGroup][2048];
 	__shared__ unsigned sel_prefix[kGroup], sel_rem[kGroup];
 	__shared__ float red[kTrimThreads / 64][2 * kGroup];
@@ -465,12 +534,12 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
 	const dim3 grid((B + kGroup - 1) / kGroup), block(kTrimThreads);
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
-	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
+	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
 	return hipGetLastError();
 }
 
-static void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts)
+__host__ __device__ inline void bounds_shape(int B, int N, int* groups, int* chunks, int* chunk_pts)
 {
 	int g = (B + kGroup - 1) / kGroup;
 	// aim for >= 4 blocks of 256 threads per CU (256 CUs) even for small batches, and
@@ -495,6 +564,30 @@ size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out)
 	if (groups_out) *groups_out = g;
 	if (chunks_out) *chunks_out = c;
 	return (size_t)g * c * 2 * kGroup;
+}
+
+size_t bounds_queue_scratch_floats(int max_groups)
+{
+	// groups x chunks partial rows: chunks <= 8 + 1024/groups (bounds_shape), so groups*chunks <= 8*groups + 4096 (margin included)
+	return (size_t)2 * kGroup * (8 * (size_t)max_groups + 4096);
+}
+
+hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
+                               int* d_work8, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream)
+{
+	if (max_groups <= 0 || N <= 0) return hipSuccess;
+	if (inliers < N) {
+		// trimmed form: one workgroup per expansion, the surplus workgroups of the fixed grid leave at once
+		const dim3 grid(max_groups), block(kTrimThreads);
+		if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
+		else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
+		return hipGetLastError();
+	}
+	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
+	else hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
+	hipLaunchKernelGGL(bounds_queue_finalize, dim3(256), dim3(256), 0, stream, scratch, d_groups, N, ub, lb);
+	return hipGetLastError();
 }
 
 hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
@@ -742,12 +835,23 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 	return r;
 }
 
-template <int K, int LAYOUT>
-__global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
-                                                               const IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
-                                                               float* __restrict__ partials)
+// Workgroup-shared state of one ICP iteration: the per-wavefront sums of the pass and the finalize's scratch, in ONE
+// __shared__ object (a second one beside it can make the compiler drain the memory pipeline before LDS reads).
+constexpr int kFinThreads = kIcpThreads;           // 256: 64 row streams x four float4 columns
+struct FinScratch { double wsum[kFinThreads / 64][kIcpAcc]; double sums[kIcpAcc]; float red[kIcpThreads / 64][kIcpAcc]; int last; };
+__device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh);
+__device__ void finalize_serial(const double* __restrict__ sums, IcpState* __restrict__ state);
+
+// FUSED: the workgroup that arrives last (one ticket per launch; agent-scope release before the ticket, acquire
+// after it -- cdna_hip_programming.md Guideline 16, counter form) also runs the finalize, so an ICP iteration is ONE
+// launch.  `ticket` is zero between launches: zeroed when the engine is created, reset by the last arriver.
+template <int K, int LAYOUT, bool FUSED>
+__global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* __restrict__ src, int N,
+                                                                  IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
+                                                                  float* __restrict__ partials, int* __restrict__ ticket)
 {
-	__shared__ float red[kIcpThreads / 64][kIcpAcc];
+	__shared__ FinScratch sh;
+	float (*red)[kIcpAcc] = sh.red;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
 	const int i = (blockIdx.x * (kIcpThreads / 64) + wave) * 4 + row;
 	const bool valid = i < N;
@@ -785,6 +889,28 @@ __global__ __launch_bounds__(kIcpThreads) void icp_pass_kernel(const float4* __r
 #pragma unroll
 		for (int x = 1; x < kIcpThreads / 64; x++) sum += red[x][threadIdx.x];
 		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = sum;
+	}
+	if constexpr (FUSED) {
+		// publish this workgroup's row: stores drained by the storing wave, workgroup barrier, then ONE lane releases
+		// at agent scope and draws the ticket (the explicit waits stay: the compiler may drop the fence's own)
+		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int last = t == (int)gridDim.x - 1;
+			if (last) {
+				__hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // next launch starts from zero
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
+			sh.last = last;
+		}
+		__syncthreads();
+		if (!sh.last) return;
+		finalize_reduce(partials, (int)gridDim.x, sh);
+		if (threadIdx.x == 0) finalize_serial(sh.sums, st);
 	}
 }
 
@@ -1080,30 +1206,28 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 		}
 }
 
-// Sum the per-wave partials in double (fixed order -> deterministic), then -- one lane -- the body of
+// Sum the per-block partials in double (fixed order -> deterministic), then -- one lane -- the body of
 // the ICP loop after the correspondence pass (jly_icp3d.hpp:253-292): convergence test, means, H,
 // SVD, R_ / t_, compose.  The pose lives in device memory, so the host can queue several iterations
-// back-to-back without a round trip.
-__global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
-                                                                     IcpState* __restrict__ state)
+// back-to-back without a round trip.  Written for one workgroup of kFinThreads threads; used by the last
+// workgroup of the fused iteration kernel and by the stand-alone finalize launch (trimmed ICP, A/B tests):
+// the same code and the same summation order, so both forms give bit-identical states.
+
+// every thread of the workgroup; returns with sh.sums[] valid for all threads
+__device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh)
 {
-	__shared__ double wsum[kIcpAcc][kIcpAcc];      // [wavefront][component]
-	__shared__ double sums[kIcpAcc];
-	// This kernel is a chain of dependent memory round trips (~1-2 us each: the partials were written
-	// by other XCDs), so everything it needs -- the state, and up to 2048 partial rows at a time as
-	// eight float4 loads per thread -- is requested before anything is waited for.  256 row streams x
-	// four float4 columns; fixed-order sums (registers, xor-butterfly inside a wavefront, then the 16
-	// wavefront totals in order): deterministic.
+	// A chain of dependent memory round trips (~1-2 us each: the partials were written by other XCDs), so the loads
+	// of a sweep -- eight float4 per thread -- are requested before anything is waited for.  64 row streams x four
+	// float4 columns; fixed-order sums (registers, xor-butterfly inside a wavefront, then the wavefront totals in order).
+	constexpr int kRows = kFinThreads / 4;
 	const int q = threadIdx.x & 3, r = threadIdx.x >> 2;
 	const float4* __restrict__ P = reinterpret_cast<const float4*>(partials);
-	IcpState st;
-	if (threadIdx.x == 0) st = *state;            // one burst of loads; the serial part below runs on registers
 	double a[4] = {0.0, 0.0, 0.0, 0.0};
-	for (int b0 = 0; b0 < nblocks; b0 += 256 * 8) {
+	for (int b0 = 0; b0 < nblocks; b0 += kRows * 8) {
 		float4 v[8];
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
-			const int b = b0 + r + 256 * j;
+			const int b = b0 + r + kRows * j;
 			v[j] = b < nblocks ? P[(size_t)b * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 #pragma unroll
@@ -1114,7 +1238,6 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 			a[3] += (double)v[j].w;
 		}
 	}
-	if (state->converged) return;                 // uniform; the pass kernel left the partials untouched
 #pragma unroll
 	for (int c = 0; c < 4; c++) {
 		double x = a[c];
@@ -1122,16 +1245,22 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 		x += __shfl_xor(x, 8, 64);
 		x += __shfl_xor(x, 16, 64);
 		x += __shfl_xor(x, 32, 64);
-		if ((threadIdx.x & 63) < 4) wsum[threadIdx.x >> 6][4 * q + c] = x;
+		if ((threadIdx.x & 63) < 4) sh.wsum[threadIdx.x >> 6][4 * q + c] = x;
 	}
 	__syncthreads();
 	if (threadIdx.x < kIcpAcc) {
 		double t = 0.0;
-		for (int i = 0; i < kIcpAcc; i++) t += wsum[i][threadIdx.x];
-		sums[threadIdx.x] = t;
+		for (int i = 0; i < kFinThreads / 64; i++) t += sh.wsum[i][threadIdx.x];
+		sh.sums[threadIdx.x] = t;
 	}
 	__syncthreads();
-	if (threadIdx.x != 0) return;
+}
+
+// one lane: the serial rest of the loop body.  __noinline__: its fp64 working set must not set the register
+// budget of the correspondence pass it is fused into (it is compiled within the caller's launch bounds).
+__device__ __noinline__ void finalize_serial(const double* __restrict__ sums, IcpState* __restrict__ state)
+{
+	IcpState st = *state;
 	const float err_new = (float)sums[15];
 	st.err_new = err_new;
 	st.passes += 1;
@@ -1184,6 +1313,15 @@ __global__ __launch_bounds__(kIcpAcc * 64) void icp_finalize_update(const float*
 	}
 	st.iters += 1;
 	*state = st;
+}
+
+__global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
+                                                                   IcpState* __restrict__ state)
+{
+	__shared__ FinScratch sh;
+	if (state->converged) return;                 // uniform; the pass kernel left the partials untouched
+	finalize_reduce(partials, nblocks, sh);
+	if (threadIdx.x == 0) finalize_serial(sh.sums, state);
 }
 
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
@@ -1254,12 +1392,12 @@ int icp_blocks(int N)
 	return (N + per_block - 1) / per_block;
 }
 
-template <int K>
-static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, hipStream_t stream)
+template <int K, bool FUSED>
+static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, int* ticket, hipStream_t stream)
 {
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
-	if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1>), grid, block, 0, stream, src, N, st, kd, dt, partials);
-	else hipLaunchKernelGGL((icp_pass_kernel<K, 0>), grid, block, 0, stream, src, N, st, kd, dt, partials);
+	if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket);
+	else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket);
 }
 
 template <int K>
@@ -1282,17 +1420,24 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 	else hipLaunchKernelGGL(icp_select_stream_kernel, dim3(1), dim3(1024), 0, stream, nn_d2, N, num, st, include);
 	const int nb = icp_trim_blocks(N);
 	hipLaunchKernelGGL(icp_accum_kernel, dim3(nb), dim3(kIcpThreads), 0, stream, src, N, st, kd, nn_d2, nn_slot, include, partials);
-	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, nb, st);
+	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, partials, nb, st);
 	return hipGetLastError();
 }
 
+// ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                hipStream_t stream)
+                                int* ticket, hipStream_t stream)
 {
-	if (kd.K == 1) launch_pass_k<1>(src, N, st, kd, dt, partials, stream);
-	else if (kd.K == 2) launch_pass_k<2>(src, N, st, kd, dt, partials, stream);
-	else launch_pass_k<3>(src, N, st, kd, dt, partials, stream);
-	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kIcpAcc * 64), 0, stream, partials, icp_blocks(N), st);
+	if (ticket) {
+		if (kd.K == 1) launch_pass_k<1, true>(src, N, st, kd, dt, partials, ticket, stream);
+		else if (kd.K == 2) launch_pass_k<2, true>(src, N, st, kd, dt, partials, ticket, stream);
+		else launch_pass_k<3, true>(src, N, st, kd, dt, partials, ticket, stream);
+		return hipGetLastError();
+	}
+	if (kd.K == 1) launch_pass_k<1, false>(src, N, st, kd, dt, partials, nullptr, stream);
+	else if (kd.K == 2) launch_pass_k<2, false>(src, N, st, kd, dt, partials, nullptr, stream);
+	else launch_pass_k<3, false>(src, N, st, kd, dt, partials, nullptr, stream);
+	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, partials, icp_blocks(N), st);
 	return hipGetLastError();
 }
 

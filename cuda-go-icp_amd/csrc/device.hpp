@@ -79,6 +79,41 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents, int B,
                               int inliers, float* ub, float* lb, hipStream_t stream);
 
+// ---- device-resident inner BnB (bnbqueue.hip): one queue per inner search, rounds without the host --------------
+constexpr int kQueueCap = 8192;     // nodes per search queue (a queue that would overflow sends the batch back to the host driver)
+constexpr int kQueueMaxPop = 32;    // most expansions per search and round
+struct QNode { float x, y, z, w, ub, lb; };                    // corner + width (TRANSNODE, jly_goicp.h:59-72)
+struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:227-340)
+	float best;                     // optErrorT (in: the incumbent; out: the search's value)
+	float coeff;                    // rotation uncertainty coefficient of this pass, 0 for the upper-bound pass
+	int32_t rot;                    // rotation slot
+	int32_t count;                  // queued nodes
+	int32_t done, improved;
+	int32_t n_parents, parent_off;  // this round's expansions in the round's list
+	int32_t pops, cubes;            // tNodeCount of this search / children evaluated
+	float bx, by, bz, bw;           // best child (corner, width), valid when improved
+};
+struct QCtl {
+	int32_t n_groups[2];            // expansions listed per round parity
+	int32_t overflow, pad;
+	int32_t work[2][8];             // per round parity and XCD slot: next work item of the bound evaluation (dynamic distribution)
+};
+struct QParams {
+	float thr;                      // SSEThresh
+	int32_t K;                      // expansions per search and round (<= kQueueMaxPop)
+	float root_x, root_y, root_z, root_w;
+	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
+	float lo[3], hi[3];
+};
+hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
+// digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
+hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
+                            const float* ubs, const float* lbs, QCtl* ctl, int parity, hipStream_t stream);
+// bounds of the 8 children of the *d_groups expansions in `parents` (count known to the device only); max_groups sizes the grids
+hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
+                               int* d_work8, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream);
+size_t bounds_queue_scratch_floats(int max_groups);
+
 // ---- ICP ------------------------------------------------------------------------------------
 // Device-resident state of the ICP loop (ICP3D<float>::Run, jly_icp3d.hpp:181-295).  One
 // iteration = icp_pass_kernel (transform, exact 1-NN, pivoted sums) + icp_finalize_update
@@ -97,8 +132,10 @@ struct IcpState {
 	int32_t frozen;              // 1: passes only score, the pose is not updated
 };
 int icp_blocks(int N);           // workgroups per pass; partials must hold icp_blocks(N)*kIcpAcc floats
+// ticket: a device int that is zero between launches -> ONE fused launch (the last workgroup to arrive runs the
+// finalize); nullptr -> two launches (pass, finalize).  Same arithmetic and summation order: bit-identical states.
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, hipStream_t stream);
+                                float* partials, int* ticket, hipStream_t stream);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,

@@ -393,8 +393,31 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		HIPCHK(hipMalloc(&d_include_, N_));
 	}
 	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
+	HIPCHK(hipMalloc(&d_icp_ticket_, 64));
+	HIPCHK(hipMemset(d_icp_ticket_, 0, 64));
 	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState)));
 	ensure_batch(4096, 64);
+	if (p_.device_queues && p_.trans_batch > 1 && p_.wide_children) {
+		// the device-resident inner-BnB queues, sized for a full round of the outer search, and their pinned mirror touched
+		// once (the first use of a fresh pinned block costs milliseconds -- measured 8 ms inside the first registration)
+		ensure_queues(1);
+		std::memset(h_qsearch_, 0, sizeof(QSearch) * cap_qsearch_);
+		HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyHostToDevice, stream_));
+		HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipStreamSynchronize(stream_));
+		// ... and one dummy search that stops at its root (incumbent 0): the first launch of each queue kernel loads its
+		// code object, which belongs to engine creation, not to the first registration
+		InnerSearch warm;
+		warm.best = 0.f;
+		std::vector<InnerSearch*> one{&warm};
+		std::vector<Rot9> rot(1);
+		const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+		std::memcpy(rot[0].r, I9, sizeof(I9));
+		run_inner_device(one, rot);
+		cnt_ = Counters{};
+		queue_rounds_ = 0;
+	}
 
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	std::memcpy(optR_, I, sizeof(I)); std::memcpy(curR_, I, sizeof(I)); std::memcpy(stepR_, I, sizeof(I));
@@ -411,12 +434,16 @@ void Engine::release()
 	if (stream_ && hipGetDevice(&prev) == hipSuccess && prev != dev_) hipSetDevice(dev_); else prev = -1;
 	if (stream_) hipStreamSynchronize(stream_);
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
+	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
+	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
+	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
+	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_);
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
-	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_);
+	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_); hipFree(d_icp_ticket_); d_icp_ticket_ = nullptr;
 	hipFree(d_nn_d2_); hipFree(d_nn_slot_); hipFree(d_include_);
 	for (Stage& st : stage_) {
 		hipFree(st.d_parents); hipFree(st.d_ub);
@@ -642,7 +669,7 @@ void Engine::icp_launch_one()
 	if (inliers_ < (int)N_)
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
-		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, stream_));
+		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr, stream_));
 }
 
 void Engine::icp_state_fetch()
@@ -761,17 +788,117 @@ void Engine::ensure_stage(int k, size_t B)
 	st.cap = cap;
 }
 
+void Engine::ensure_queues(size_t nsearch)
+{
+	if (nsearch <= cap_qsearch_) return;
+	// first use: room for a full round of the outer search (rot_batch parents x 8 children x {ub, lb} pass) -- growing in
+	// steps would re-allocate the 196 KB-per-search slabs several times in the first rounds
+	size_t cap = std::max<size_t>(cap_qsearch_, p_.wide_children ? (size_t)16 * (size_t)std::max(1, p_.rot_batch) : 16);
+	while (cap < nsearch) cap *= 2;
+	HIPCHK(hipStreamSynchronize(stream_));
+	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
+	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_);
+	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
+	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
+	const size_t max_groups = cap * kQueueMaxPop;
+	HIPCHK(hipMalloc(&d_qsearch_, sizeof(QSearch) * cap));
+	HIPCHK(hipHostMalloc(&h_qsearch_, sizeof(QSearch) * cap));
+	HIPCHK(hipMalloc(&d_qnodes_, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
+	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qparents_[k], sizeof(ParentRec) * max_groups));
+	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
+	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
+	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups)));
+	if (!d_qctl_) {
+		HIPCHK(hipMalloc(&d_qctl_, sizeof(QCtl)));
+		HIPCHK(hipHostMalloc(&h_qctl_, sizeof(QCtl)));
+	}
+	cap_qsearch_ = cap;
+}
+
+// The inner searches with their queues on the device: a round = bnb_queue_kernel (digest the previous round's
+// bounds, select the next expansions) + the bound evaluation of the listed expansions; the host queues rounds and
+// looks at one word every few rounds.  Same bounds, same stop and prune rules as run_inner_host.
+bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
+{
+	const size_t S = searches.size(), nrot = rots.size();
+	const int K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
+	ensure_queues(S);
+	ensure_batch(1, nrot);
+	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
+	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * nrot, hipMemcpyHostToDevice, stream_));
+	for (size_t i = 0; i < S; i++) {
+		QSearch& q = h_qsearch_[i];
+		std::memset(&q, 0, sizeof(q));
+		q.best = searches[i]->best; q.coeff = searches[i]->coeff; q.rot = searches[i]->rot_slot;
+	}
+	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * S, hipMemcpyHostToDevice, stream_));
+	QParams qp{};
+	qp.thr = sse_thresh_; qp.K = K;
+	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
+	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
+	for (int k = 0; k < 3; k++) { qp.lo[k] = trans_boxed_ ? trans_lo_[k] : 0.f; qp.hi[k] = trans_boxed_ ? trans_hi_[k] : 0.f; }
+	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
+	const int max_groups = (int)(S * (size_t)K);
+	int parity = 0, chunk = 3;
+	while (true) {
+		const double t0 = now_ms();
+		int last = 0;
+		for (int r = 0; r < chunk; r++) {
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qctl_, parity, stream_));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, dt_, d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], max_groups,
+			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+			last = parity;
+			parity ^= 1;
+			cnt_.bounds_launches++;
+			queue_rounds_++;
+		}
+		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		t_submit_ += now_ms() - t0;
+		const double t1 = now_ms();
+		HIPCHK(hipStreamSynchronize(stream_));
+		t_wait_ += now_ms() - t1;
+		if (h_qctl_->overflow) { queue_fallbacks_++; return false; }
+		if (h_qctl_->n_groups[last] == 0 || cancel_.load()) break;
+		chunk = 4;
+	}
+	const double t2 = now_ms();
+	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	for (size_t i = 0; i < S; i++) {
+		const QSearch& q = h_qsearch_[i];
+		InnerSearch& s = *searches[i];
+		s.best = q.best; s.improved = q.improved != 0; s.done = true;
+		s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
+		s.pops = q.pops; s.cubes = q.cubes;
+	}
+	t_collect_ += now_ms() - t2;
+	return true;
+}
+
+void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
+{
+	DeviceGuard guard(dev_);
+	for (auto* s : searches)
+		if (s->rot_slot < 0 || (size_t)s->rot_slot >= rots.size()) throw std::logic_error("goicp: rotation slot out of range");
+	if (p_.device_queues && p_.trans_batch > 1) {
+		const double t_begin = now_ms();
+		const bool ok = run_inner_device(searches, rots);
+		bnb_ms_ += now_ms() - t_begin;
+		if (ok) return;
+		// a queue outgrew its slab: the batch is re-run through the host queues (the searches have not been touched)
+	}
+	run_inner_host(searches, rots);
+}
+
 // Lock-step rounds of all the given inner searches: pop up to trans_batch nodes per search, evaluate the
 // 8 children of every popped node in ONE launch, digest the bounds, repeat until every search stops.
-void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
+void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
 {
 	DeviceGuard guard(dev_);
 	const double t_begin = now_ms();
 	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
 	const int K = std::max(1, p_.trans_batch);
 	const size_t nrot = rots.size();
-	for (auto* s : searches)
-		if (s->rot_slot < 0 || (size_t)s->rot_slot >= nrot) throw std::logic_error("goicp: rotation slot out of range");
 	ensure_batch(1, nrot);
 	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
 	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * nrot, hipMemcpyHostToDevice, stream_));
@@ -809,6 +936,7 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 			for (const Node& par : s->parents) {
 				// the kernels expand the 8 children themselves (load_group in device.hip; jly_goicp.cpp:262-273)
 				ParentRec& r = st.h_parents[o++];
+				if (p_.verbose) { int lv = 0; for (float w = par.w; w < trans_root_.w && lv < 31; w *= 2) lv++; level_hist_[lv]++; }
 				r.x = par.x; r.y = par.y; r.z = par.z; r.w = par.w; r.coeff = s->coeff; r.rot = s->rot_slot;
 			}
 		st.B = B;
@@ -936,6 +1064,7 @@ void Engine::register_begin()
 	early_exit_ = converged_ = false;
 	rot_ramp_ = 8;
 	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
+	std::memset(level_hist_, 0, sizeof(level_hist_));
 	cnt_ = Counters{};
 	while (!queue_.empty()) queue_.pop();
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -1100,6 +1229,35 @@ StepStatus Engine::register_step(int max_rot_pops)
 	return st;
 }
 
+int Engine::donate(int max_nodes, float* out)
+{
+	// every second cube in priority order leaves (at most max_nodes, never the whole queue): both sides keep
+	// cubes of every priority, and the frontier's minimum lower bound stays with the donor
+	std::vector<Node> all;
+	all.reserve(queue_.size());
+	while (!queue_.empty()) { all.push_back(queue_.top()); queue_.pop(); }
+	int n = 0;
+	for (size_t i = 0; i < all.size(); i++) {
+		if ((i & 1) && n < max_nodes) {
+			const Node& c = all[i];
+			float* o = out + 7 * n++;
+			o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = c.ub; o[5] = c.lb; o[6] = (float)c.l;
+		} else queue_.push(all[i]);
+	}
+	return n;
+}
+
+void Engine::receive(const float* in, int n)
+{
+	for (int i = 0; i < n; i++) {
+		const float* o = in + 7 * i;
+		Node c{o[0], o[1], o[2], o[3], o[4], o[5], (int)o[6]};
+		if (c.lb < opt_err_) queue_.push(c);
+	}
+	if (!queue_.empty() && !early_exit_) converged_ = false;
+	publish(false);
+}
+
 void Engine::register_end()
 {
 	publish(true);
@@ -1118,6 +1276,11 @@ void Engine::run()
 	if (p_.verbose)
 		std::fprintf(stderr, "[goicp] register %.2f ms: inner BnB rounds %.2f ms (%lld launches: host build %.2f, GPU wait %.2f, host digest %.2f), ICP + DT re-score %.2f ms (%lld passes)\n",
 		             register_ms_, bnb_ms_, cnt_.bounds_launches, t_submit_, t_wait_, t_collect_, icp_ms_, cnt_.icp_iters);
+	if (p_.verbose) {
+		std::fprintf(stderr, "[goicp] translation expansions by parent depth:");
+		for (int l = 0; l < 32; l++) if (level_hist_[l]) std::fprintf(stderr, " %d:%lld", l, level_hist_[l]);
+		std::fprintf(stderr, "\n");
+	}
 	register_end();
 }
 

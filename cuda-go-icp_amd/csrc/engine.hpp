@@ -29,6 +29,8 @@ struct Params {
 	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d order (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
+	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
+	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 	// Search domain ([params.rotation] / [params.translation] of the reference's configs, test/skull_goicp.toml:22-41;
 	// declared in src/common.h:157-169, never parsed there).  Unset = the CPU path's fixed domain
@@ -107,6 +109,10 @@ public:
 	StepStatus register_step(int max_rot_pops);
 	void offer_global_best(float sse, const float R[9], const float t[3]);   // result of the min all-reduce
 	void register_end();
+	// rebalancing between ranks (shard.cpp): cubes still worth expanding / give every second one away / take some
+	int queue_size() const { return (early_exit_ || converged_) ? 0 : (int)queue_.size(); }
+	int donate(int max_nodes, float* nodes7);
+	void receive(const float* nodes7, int n);
 
 	// ---- inspection ----
 	const DtDesc& dt() const { return dt_; }
@@ -129,6 +135,9 @@ private:
 	void ensure_batch(size_t B, size_t K);
 	void ensure_stage(int k, size_t B);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
+	void run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
+	bool run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);   // false: a queue overflowed, nothing was changed
+	void ensure_queues(size_t nsearch);
 	void process_parents(const std::vector<Node>& parents);
 	void adopt(float err, const float R[9], const float t[3]);
 	float icp_from(float R[9], float t[3]);
@@ -184,8 +193,17 @@ private:
 		float* d_ub = nullptr; float* h_ub = nullptr;   // ub[B] followed by lb[B]
 		size_t cap = 0, B = 0; hipEvent_t ev = nullptr;
 	} stage_[2];
+	// device-resident inner-BnB queues (bnbqueue.hip)
+	size_t cap_qsearch_ = 0;
+	QSearch* d_qsearch_ = nullptr; QSearch* h_qsearch_ = nullptr;
+	QNode* d_qnodes_ = nullptr;
+	ParentRec* d_qparents_[2] = {nullptr, nullptr};
+	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
+	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;
+	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
+	int* d_icp_ticket_ = nullptr;      // arrival ticket of the fused ICP iteration (zero between launches)
 	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only
 	void icp_launch_one();
 	// nn query staging grows on demand
@@ -202,6 +220,7 @@ private:
 	std::mutex mtx_;
 	Result snap_{};
 	double dt_build_ms_ = 0, register_ms_ = 0, bnb_ms_ = 0, icp_ms_ = 0, t_submit_ = 0, t_wait_ = 0, t_collect_ = 0;
+	long long level_hist_[32] = {};   // verbose: translation expansions by parent depth
 	// icp_step state
 	float stepR_[9], stepT_[3];
 };

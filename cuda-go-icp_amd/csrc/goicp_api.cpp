@@ -3,8 +3,11 @@
 #include "../../include/goicp_mi355.h"
 
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "config_io.hpp"
 #include "engine.hpp"
@@ -12,6 +15,18 @@
 struct goicp_engine {
 	goicp::Engine* e;
 };
+
+namespace goicp {
+int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, int rot_pops_per_step, int rebalance, goicp_shard_stats* stats);
+int thread_comm_create(int world, goicp_comm_ops* out);
+void thread_comm_destroy(goicp_comm_ops* comm);
+int rccl_unique_id(char id128[GOICP_RCCL_ID_BYTES]);
+int rccl_comm_create(const char id128[GOICP_RCCL_ID_BYTES], int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
+int rccl_comm_wrap(void* nccl_comm, int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
+int rccl_comm_destroy(goicp_comm_ops* comm);
+int rccl_comm_init_all(int world, void** comms);
+void rccl_comm_destroy_raw(void* comm);
+}  // namespace goicp
 
 namespace {
 
@@ -97,6 +112,7 @@ void goicp_params_default(goicp_params* p)
 		p->trans_min[k] = d.trans_min[k]; p->trans_max[k] = d.trans_max[k];
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
+	p->icp_fused = d.icp_fused; p->device_queues = d.device_queues;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -139,6 +155,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 				p.trans_min[k] = params->trans_min[k]; p.trans_max[k] = params->trans_max[k];
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
+			p.icp_fused = params->icp_fused; p.device_queues = params->device_queues;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }
@@ -367,6 +384,131 @@ int goicp_register_end(goicp_handle h)
 {
 	REQUIRE(h);
 	return guarded([&] { h->e->register_end(); });
+}
+
+// ---- sharded registration: the engine as the protocol's callback table ---------------------------------------------
+namespace {
+goicp::Engine* E(void* ctx) { return static_cast<goicp_engine*>(ctx)->e; }
+int eo_begin(void* c, int32_t rank, int32_t world) { return guarded([&] { E(c)->set_shard(rank, world); E(c)->register_begin(); }); }
+int eo_step(void* c, int32_t max_pops, goicp_step_status* out) { return goicp_register_step(static_cast<goicp_engine*>(c), max_pops, out); }
+int eo_pose(void* c, float* sse, float R[9], float t[3])
+{
+	return guarded([&] {
+		const goicp::Result r = E(c)->poll();
+		*sse = r.best_sse;
+		std::memcpy(R, r.optR, sizeof(r.optR));
+		std::memcpy(t, r.optT, sizeof(r.optT));
+	});
+}
+int eo_offer(void* c, float sse, const float R[9], const float t[3]) { return guarded([&] { E(c)->offer_global_best(sse, R, t); }); }
+int eo_qsize(void* c, int32_t* n) { *n = E(c)->queue_size(); return GOICP_OK; }
+int eo_donate(void* c, int32_t max_nodes, float* nodes7, int32_t* n) { return guarded([&] { *n = E(c)->donate(max_nodes, nodes7); }); }
+int eo_receive(void* c, const float* nodes7, int32_t n) { return guarded([&] { E(c)->receive(nodes7, n); }); }
+int eo_end(void* c) { return guarded([&] { E(c)->register_end(); }); }
+}  // namespace
+
+int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
+                      goicp_shard_stats* stats)
+{
+	REQUIRE(engine && comm && engine->begin && engine->step && engine->pose && engine->offer && engine->queue_size && engine->donate &&
+	        engine->receive && engine->end && comm->allreduce_min_u64 && comm->bcast);
+	int rc = GOICP_ERR_INTERNAL;
+	const int g = guarded([&] { rc = goicp::run_sharded(engine, comm, rot_pops_per_step, rebalance, stats); });
+	if (g != GOICP_OK) return g;
+	if (rc != GOICP_OK && g_err.empty()) g_err = "sharded registration: a callback failed";
+	return rc;
+}
+
+int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance, goicp_shard_stats* stats)
+{
+	REQUIRE(h && comm);
+	goicp_shard_engine_ops eo{};
+	eo.ctx = h; eo.sse_threshold = h->e->sse_threshold();
+	eo.begin = eo_begin; eo.step = eo_step; eo.pose = eo_pose; eo.offer = eo_offer; eo.queue_size = eo_qsize;
+	eo.donate = eo_donate; eo.receive = eo_receive; eo.end = eo_end;
+	return goicp_run_sharded(&eo, comm, rot_pops_per_step, rebalance, stats);
+}
+
+int goicp_thread_comm_create(int32_t world, goicp_comm_ops* out)
+{
+	REQUIRE(out && world >= 1 && world <= 1024);
+	return guarded([&] { if (goicp::thread_comm_create(world, out) != GOICP_OK) throw std::bad_alloc(); });
+}
+int goicp_thread_comm_destroy(goicp_comm_ops* comm) { goicp::thread_comm_destroy(comm); return GOICP_OK; }
+
+int goicp_rccl_unique_id(char id128[GOICP_RCCL_ID_BYTES])
+{
+	REQUIRE(id128);
+	const int rc = goicp::rccl_unique_id(id128);
+	return rc == GOICP_OK ? rc : fail(rc, "ncclGetUniqueId failed");
+}
+
+int goicp_rccl_comm_create(const char id128[GOICP_RCCL_ID_BYTES], int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out)
+{
+	REQUIRE(id128 && out && world >= 1 && rank >= 0 && rank < world && device >= 0);
+	const int rc = goicp::rccl_comm_create(id128, rank, world, device, out);
+	return rc == GOICP_OK ? rc : fail(rc, "RCCL communicator creation failed (ncclCommInitRank / staging buffers)");
+}
+
+int goicp_rccl_comm_wrap(void* nccl_comm, int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out)
+{
+	REQUIRE(nccl_comm && out && world >= 1 && rank >= 0 && rank < world && device >= 0);
+	const int rc = goicp::rccl_comm_wrap(nccl_comm, rank, world, device, out);
+	return rc == GOICP_OK ? rc : fail(rc, "RCCL communicator staging buffers could not be created");
+}
+
+int goicp_rccl_comm_destroy(goicp_comm_ops* comm) { return goicp::rccl_comm_destroy(comm); }
+
+int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz, size_t n_target, const float* source_xyz, size_t n_source,
+                             int32_t world, int32_t rot_pops_per_step, goicp_handle* out, goicp_shard_stats* stats)
+{
+	REQUIRE(out && target_xyz && source_xyz && n_target > 0 && n_source > 0 && world >= 1 && world <= 64 && rot_pops_per_step >= 1);
+	*out = nullptr;
+	goicp_params base;
+	if (params) base = *params; else goicp_params_default(&base);
+	std::vector<goicp_handle> hs((size_t)world, nullptr);
+	std::vector<void*> raw((size_t)world, nullptr);
+	std::vector<goicp_comm_ops> comms((size_t)world);
+	std::vector<int> rcs((size_t)world, GOICP_OK);
+	std::vector<std::string> errs((size_t)world);
+	int rc = GOICP_OK;
+	auto cleanup = [&](bool keep0) {
+		for (int r = 0; r < world; r++) {
+			goicp_rccl_comm_destroy(&comms[(size_t)r]);
+			goicp::rccl_comm_destroy_raw(raw[(size_t)r]);
+			if (!(keep0 && r == 0)) goicp_destroy(hs[(size_t)r]);
+		}
+	};
+	for (int r = 0; r < world; r++) std::memset(&comms[(size_t)r], 0, sizeof(goicp_comm_ops));
+	// one engine per GPU, created side by side (DT + k-d builds overlap)
+	{
+		std::vector<std::thread> th;
+		for (int r = 0; r < world; r++)
+			th.emplace_back([&, r] {
+				goicp_params p = base;
+				p.device = r;
+				rcs[(size_t)r] = goicp_create(&p, target_xyz, n_target, source_xyz, n_source, &hs[(size_t)r]);
+				if (rcs[(size_t)r] != GOICP_OK) errs[(size_t)r] = goicp_last_error();
+			});
+		for (auto& t : th) t.join();
+	}
+	for (int r = 0; r < world; r++) if (rcs[(size_t)r] != GOICP_OK) { rc = rcs[(size_t)r]; g_err = errs[(size_t)r]; }
+	if (rc == GOICP_OK && goicp::rccl_comm_init_all(world, raw.data()) != GOICP_OK) rc = fail(GOICP_ERR_DEVICE, "ncclCommInitAll failed");
+	for (int r = 0; rc == GOICP_OK && r < world; r++) rc = goicp_rccl_comm_wrap(raw[(size_t)r], r, world, r, &comms[(size_t)r]);
+	if (rc != GOICP_OK) { cleanup(false); return rc; }
+	{
+		std::vector<std::thread> th;
+		for (int r = 0; r < world; r++)
+			th.emplace_back([&, r] {
+				rcs[(size_t)r] = goicp_register_sharded(hs[(size_t)r], &comms[(size_t)r], rot_pops_per_step, 1, stats ? &stats[r] : nullptr);
+				if (rcs[(size_t)r] != GOICP_OK) errs[(size_t)r] = goicp_last_error();
+			});
+		for (auto& t : th) t.join();
+	}
+	for (int r = 0; r < world; r++) if (rcs[(size_t)r] != GOICP_OK) { rc = rcs[(size_t)r]; g_err = errs[(size_t)r]; }
+	cleanup(rc == GOICP_OK);
+	if (rc == GOICP_OK) *out = hs[0];
+	return rc;
 }
 
 }  // extern "C"

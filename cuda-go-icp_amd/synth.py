@@ -23,7 +23,7 @@ def _rodrigues(v):
     return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
 
 
-def _surface(rng, n, coef):
+def _surface(rng, n, coef, amp=0.35):
     # uniform directions; radius from low-order harmonics with odd terms (x, y, z, xyz) so that the
     # shape has no rotational or point symmetry (a near-sphere would make Go-ICP's early exit
     # accept any rotation).  Radius stays in [0.25, 0.95].  Not area-uniform; irrelevant here.
@@ -31,16 +31,18 @@ def _surface(rng, n, coef):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     x, y, z = d.T
     basis = np.stack([x, y, z, x * y, y * z, 3 * z * z - 1, x * x - y * y, 5 * x * y * z], axis=1)
-    r = 0.6 + 0.35 * np.tanh(basis @ coef)
+    r = 0.6 + amp * np.tanh(basis @ coef)
     return d * r[:, None]
 
 
-def make_pair(seed=S1["seed"], M=S1["M"], N=S1["N"], noise=0.002, V=None):
-    """-> (target (M,3) f32, source (N,3) f32, R_gt (3,3), t_gt (3,)) with target ~= R_gt*source + t_gt."""
+def make_pair(seed=S1["seed"], M=S1["M"], N=S1["N"], noise=0.002, V=None, amp=0.35):
+    """-> (target (M,3) f32, source (N,3) f32, R_gt (3,3), t_gt (3,)) with target ~= R_gt*source + t_gt.
+    amp = relief of the surface (0.35: strongly non-symmetric, ICP's basin of convergence is wide; smaller values
+    approach a sphere: many shallow local minima, the BnB has to dig for the true basin)."""
     rng = np.random.default_rng(seed)
     coef = rng.uniform(-1, 1, size=8)
-    target = _surface(rng, M, coef)
-    moved = _surface(rng, N, coef) + rng.normal(scale=noise, size=(N, 3))
+    target = _surface(rng, M, coef, amp)
+    moved = _surface(rng, N, coef, amp) + rng.normal(scale=noise, size=(N, 3))
     R = _rodrigues(GT_AXIS_ANGLE)
     # source = R^T (moved - t)  =>  R*source + t = moved, which lies on the target surface
     source = (moved - GT_T) @ R

@@ -112,6 +112,11 @@ typedef struct goicp_params {
 	float rot_min[3], rot_max[3];       /* degrees; components of the angle-axis vector */
 	float trans_min[3], trans_max[3];   /* in cloud units after `resize` */
 	int32_t rot_search_depth, trans_search_depth;
+	int32_t icp_fused;       /* 1: one launch per ICP iteration, the last workgroup to arrive runs the update;
+	                          * 0: correspondence pass + update as two launches (same arithmetic, bit-identical states) */
+	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner
+	                          * searches is two launches, no host round trip; 0: host-side queues (always used with trans_batch == 1,
+	                          * the reference visit order) */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);
@@ -239,6 +244,63 @@ int goicp_register_begin(goicp_handle h);
 int goicp_register_step(goicp_handle h, int32_t max_rot_pops, goicp_step_status* out);
 int goicp_offer_best(goicp_handle h, float sse, const float R[9], const float t[3]);
 int goicp_register_end(goicp_handle h);
+
+/* ---- the sharded registration inside the library (csrc/shard.cpp, csrc/rccl_comm.cpp) ------------------------------
+ * One call per rank drives the whole protocol: step the local search, ONE all-reduce(MIN) of five packed 64-bit words
+ * per step ({best SSE, rank}, frontier lower bound, early-exit / active / idle flags), a 48-byte broadcast of the winner's
+ * R|t only when the global best moved, global termination, and -- when a rank runs dry -- rebalancing (queue sizes
+ * gathered, every second cube of the largest queue broadcast to the idle rank).
+ * The communicator is a callback table, so the protocol also runs (and is tested) without RCCL. */
+typedef struct goicp_comm_ops {
+	void* ctx;
+	int32_t rank, world;
+	/* element-wise MIN over the ranks of n unsigned 64-bit words, in place; blocking */
+	int (*allreduce_min_u64)(void* ctx, uint64_t* words, size_t n);
+	/* broadcast `bytes` bytes from rank `root`; blocking */
+	int (*bcast)(void* ctx, void* buf, size_t bytes, int32_t root);
+} goicp_comm_ops;
+typedef struct goicp_shard_stats {
+	int64_t steps, exchanges, broadcasts, donations, donated_cubes;
+	float best_sse;
+} goicp_shard_stats;
+/* the engine side of the protocol as a callback table (goicp_register_sharded fills it for a real engine; tests
+ * supply a CPU stand-in).  nodes7: 7 floats per rotation cube {corner x,y,z, width, ub, lb, level}. */
+typedef struct goicp_shard_engine_ops {
+	void* ctx;
+	float sse_threshold;
+	int (*begin)(void* ctx, int32_t rank, int32_t world);
+	int (*step)(void* ctx, int32_t max_rot_pops, goicp_step_status* out);
+	int (*pose)(void* ctx, float* sse, float R[9], float t[3]);
+	int (*offer)(void* ctx, float sse, const float R[9], const float t[3]);
+	int (*queue_size)(void* ctx, int32_t* n);
+	int (*donate)(void* ctx, int32_t max_nodes, float* nodes7, int32_t* n);
+	int (*receive)(void* ctx, const float* nodes7, int32_t n);
+	int (*end)(void* ctx);
+} goicp_shard_engine_ops;
+int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, int32_t rot_pops_per_step,
+                      int32_t rebalance, goicp_shard_stats* stats);
+/* the same for an engine handle (blocking; one call per rank, each rank with its own engine on its own GPU) */
+int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
+                           goicp_shard_stats* stats);
+/* in-process communicator: `world` host threads of ONE process, rank r calling with out[r] (tests; rehearsing the
+ * N-rank path with N engines on one GPU).  Destroy every element. */
+int goicp_thread_comm_create(int32_t world, goicp_comm_ops* out /* [world] */);
+int goicp_thread_comm_destroy(goicp_comm_ops* comm);
+/* RCCL communicator (ncclAllReduce / ncclBroadcast over xGMI on a stream of its own, separate from the engine's compute
+ * stream).  id128: an ncclUniqueId (128 bytes) made by ONE rank with goicp_rccl_unique_id() and handed to the others
+ * by whatever launched them (MPI, torch.distributed, a file); goicp_rccl_comm_create() is collective.  `device` = the
+ * HIP device of this rank. */
+#define GOICP_RCCL_ID_BYTES 128
+int goicp_rccl_unique_id(char id128[GOICP_RCCL_ID_BYTES]);
+int goicp_rccl_comm_create(const char id128[GOICP_RCCL_ID_BYTES], int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
+/* wrap an existing ncclComm_t (e.g. one of ncclCommInitAll's); the communicator stays the caller's */
+int goicp_rccl_comm_wrap(void* nccl_comm, int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
+int goicp_rccl_comm_destroy(goicp_comm_ops* comm);
+/* single-process form: `world` engines (one per GPU, device r for rank r) created from the same clouds and driven by
+ * `world` host threads over ncclCommInitAll -- what goicp_cli --ranks N runs.  Results: rank 0's engine handle is
+ * returned in *out (poll / write it like any other); stats per rank optional ([world]). */
+int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz, size_t n_target, const float* source_xyz,
+                             size_t n_source, int32_t world, int32_t rot_pops_per_step, goicp_handle* out, goicp_shard_stats* stats);
 
 /* ---- measurement / test helpers ----------------------------------------------------------------
  * goicp_probe_gather: measured ceiling of the path that bounds the cube-bound kernel -- independent 4-byte loads

@@ -108,3 +108,22 @@ class FakeEngine:
 
     def register_end(self):
         pass
+
+    # ---- rebalancing hooks of the library's protocol (csrc/shard.cpp) ----
+    def queue_size(self):
+        return 0 if (self.early or self.conv) else len(self.q)
+
+    def donate(self, max_nodes):
+        items = sorted(self.q)
+        give = [it for i, it in enumerate(items) if i & 1][:max_nodes]
+        keep = [it for it in items if all(it is not g for g in give)]
+        self.q = keep
+        heapq.heapify(self.q)
+        return [(n[0], n[1], n[2], n[3], 0.0, lb, n[4]) for lb, _, _, n in give]
+
+    def receive(self, nodes):
+        for x, y, z, w, ub, lb, l in nodes:
+            if lb < self.best:
+                self._push(lb, (np.float32(x), np.float32(y), np.float32(z), np.float32(w), int(l)))
+        if self.q and not self.early:
+            self.conv = False

@@ -20,10 +20,24 @@ if which == "spanner":
         print("spanner mse %g: create %.2fs run %.3fs sse %.4f rot_err %.5f t_err %.5f rot_pops %d cubes %d icp %d launches %d" % (
             mse, t1 - t0, t2 - t1, eng.get_best_error(), rot_angle(eng.optR, Rgt), np.linalg.norm(eng.optT - tgt), c.rot_pops, c.cubes, c.icp_iters, c.bounds_launches), flush=True)
         eng.registration.close()
+elif which == "bunny":
+    for dq in (1, 0, 1, 0):
+        eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, verbose=1, device_queues=dq)
+        t1 = time.time(); eng.run(); c = eng.counters
+        print("bunny device_queues=%d run %.4fs sse %.4f rot_pops %d trans_pops %d cubes %d launches %d icp %d" % (
+            dq, time.time() - t1, eng.get_best_error(), c.rot_pops, c.trans_pops, c.cubes, c.bounds_launches, c.icp_iters), flush=True)
+        eng.registration.close()
 else:
     from cuda_go_icp_amd import synth
-    target, source, Rgt, tgt = synth.make_pair(**{k: synth.S2[k] for k in ("seed", "M", "N")})
-    for mse in [float(x) for x in sys.argv[2:]] or [1e-4, 3e-5, 2e-5, 1.5e-5]:
+    amp = float(os.environ.get("AMP", "0.35"))
+    nn = int(os.environ.get("NPTS", "1000000"))
+    target, source, Rgt, tgt = synth.make_pair(seed=synth.S2["seed"], M=nn, N=nn, amp=amp)
+    print("amp", amp, "N", nn, flush=True)
+    probe = pkg.Registration(target, source, 1e-3, dt_size=512)
+    floor = float(probe.compute_sse_error(Rgt, tgt)) / len(source)
+    probe.close()
+    print("floor mse at the GT pose", floor, flush=True)
+    for mse in [float(x) * (floor if float(x) >= 1 else 1) for x in sys.argv[2:]] or [1e-4, 3e-5, 2e-5, 1.5e-5]:
         t0 = time.time(); eng = pkg.FastGoICP(target, source, mse, dt_size=512, verbose=1); t1 = time.time()
         print("sse at GT pose:", eng.registration.compute_sse_error(Rgt, tgt), "thr", eng.sse_threshold, flush=True)
         eng.run(); t2 = time.time()

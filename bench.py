@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--kd-gpu-build", type=int, default=-1, help="tuning only: target hierarchy built on the device 1 / host 0 / auto -1")
     ap.add_argument("--morton", type=int, default=2, help="tuning only: source order 0 input / 1 Morton / 2 k-d order")
     ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--bounds-fp16", type=int, default=0, help="opt-in half-precision DT copy for the BnB bounds (not the bit-parity path)")
+    ap.add_argument("--icp-fused", type=int, default=-1, help="tuning only: ICP iteration as one fused launch 1 / pass + finalize 0 / engine default -1")
+    ap.add_argument("--device-queues", type=int, default=1, help="tuning only: inner-BnB queues on the device 1 / host 0")
     ap.add_argument("--no-probe", action="store_true", help="profiling runs: skip the gather-ceiling probes and the generic-path leg")
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
                     help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")
@@ -206,7 +209,8 @@ def main():
     N, M, V = len(data), len(model), args.dt_size
 
     t_create = time.perf_counter()
-    reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, morton_sort=args.morton, kd_gpu_build=args.kd_gpu_build)
+    reg = pkg.Registration(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, morton_sort=args.morton, kd_gpu_build=args.kd_gpu_build,
+                           bounds_fp16=args.bounds_fp16, **({"icp_fused": args.icp_fused} if args.icp_fused >= 0 else {}))
     t_create = time.perf_counter() - t_create
     lib, h = reg._lib, reg.handle
     rots, recs, n_lb = make_batch(pkg, reg, args.expansions, 8, seed=1234 + rank)
@@ -252,19 +256,40 @@ def main():
             from cuda_go_icp_amd import sharded, synth
             tgt, srcc, Rgt, tgt_t = synth.make_pair(seed=synth.S1["seed"], M=40000, N=40000, noise=0.01)
             eng = pkg.FastGoICP(tgt, srcc, 1e-3, dt_size=300, device=local_rank)
+            # the exchange runs inside the library (csrc/shard.cpp) over its own RCCL communicator (csrc/rccl_comm.cpp):
+            # rank 0 makes the ncclUniqueId, torch.distributed only carries those 128 bytes to the other ranks
+            if args.backend == "nccl":
+                ident = C.create_string_buffer(128)
+                if rank == 0:
+                    B.check(lib.goicp_rccl_unique_id(ident))
+                idt = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+                dist.broadcast(idt, src=0)
+                ident = C.create_string_buffer(bytes(idt.cpu().tolist()), 128)
+                comm = B.CCommOps()
+                B.check(lib.goicp_rccl_comm_create(ident, rank, world, local_rank, C.byref(comm)))
+                exchange = "library protocol over RCCL (ncclAllReduce MIN of 5 packed u64 + ncclBroadcast of R|t on change + rebalancing)"
+            else:
+                comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
+                exchange = "library protocol over torch.distributed gloo (rehearsal)"
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            sse, Rr, tr, stats = sharded.run_sharded(eng, sharded.TorchExchange(dist, dev), rot_pops_per_step=4)
+            lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=4)
             wall = time.perf_counter() - t1
+            sse, Rr, tr = eng.pose()
+            Rr = Rr.reshape(3, 3)
+            stats = {"exchanges": lstats["exchanges"], "donations": lstats["donations"], "broadcasts": lstats["broadcasts"], "exchange": exchange}
+            if args.backend == "nccl":
+                B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
             c = eng.counters
             tot = torch.tensor([float(c.cubes), float(c.rot_pops), wall], dtype=torch.float64, device=dev)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
             sharded_res = {"workload": "synthetic S1 surface, N=M=40000, noise sigma 0.01 (spanner_goicp class), DT 300^3",
                            "wall_s": round(wall, 4), "sse": float(sse), "cube_bounds_all_ranks": int(tot[0].item()),
-                           "rot_pops_all_ranks": int(tot[1].item()), "exchanges": stats["exchanges"],
+                           "rot_pops_all_ranks": int(tot[1].item()), "exchanges": stats["exchanges"], "pose_broadcasts": stats["broadcasts"],
+                           "donations": stats["donations"], "exchange": stats["exchange"],
                            "rot_error_rad": round(ang, 5), "trans_error": round(float(np.linalg.norm(tr - tgt_t)), 5)}
             eng.registration.close()
         except Exception as e:      # reported, never fatal for the headline line
@@ -309,7 +334,9 @@ def main():
         # (goicp_probe_gather): coalesced / fully divergent, from an L1-sized, an L2-sized and the whole-grid window.
         probe = {}
         for name, mode, window in () if args.no_probe else (("coalesced_l1", 0, 16 << 10), ("coalesced_l2", 0, 2 << 20), ("coalesced_dt", 0, 1 << 40),
-                                   ("divergent_l1", 1, 16 << 10), ("divergent_l2", 1, 2 << 20), ("divergent_dt", 1, 1 << 40)):
+                                   ("divergent_l1", 1, 16 << 10), ("divergent_l2", 1, 2 << 20), ("divergent_dt", 1, 1 << 40),
+                                   ("lines4_l2", 4, 2 << 20), ("lines8_l2", 8, 2 << 20), ("lines16_l2", 16, 2 << 20), ("lines32_l2", 32, 2 << 20),
+                                   ("lines16_l1", 16, 64 << 10), ("lines32_l1", 32, 64 << 10)):
             v = C.c_double()
             B.check(lib.goicp_probe_gather(h, mode, window, C.byref(v)))
             probe[name] = round(v.value / 1e9, 2)
@@ -388,7 +415,8 @@ def main():
         # ---- end-to-end registration of the same clouds ----
         e2e = None
         if not args.no_e2e:
-            eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, kd_gpu_build=args.kd_gpu_build)
+            eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, kd_gpu_build=args.kd_gpu_build,
+                                bounds_fp16=args.bounds_fp16, device_queues=args.device_queues, **({"icp_fused": args.icp_fused} if args.icp_fused >= 0 else {}))
             t1 = time.perf_counter()
             eng.run()
             wall = time.perf_counter() - t1

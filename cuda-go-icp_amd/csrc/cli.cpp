@@ -1,5 +1,7 @@
 // goicp_cli: headless replacement for the reference's viewer main (src/main.cpp:14-187).  Takes the
-// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S]
+// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N]
+//   --ranks N   (modes 3/4) shard the rotation-cube search over N GPUs of this node: N engines (device r for rank r),
+//               N host threads, RCCL all-reduce / broadcast over xGMI (goicp_register_multi_gpu)
 //   modes 0/1/2 (plain ICP, src/main.cpp:99-110): N ICP iterations (the reference iterates forever; default 50)
 //   modes 3/4   (Go-ICP,   src/main.cpp:111-141): full registration
 // Prints the result the way the reference logs it and writes io.output (output.toml) when set.
@@ -26,8 +28,8 @@ static std::string resolve(const std::string& p, const std::string& toml)
 
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S]\n"); return 2; }
-	int iters = 50, verbose = 0;
+	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N]\n"); return 2; }
+	int iters = 50, verbose = 0, ranks = 1;
 	float trim_fraction = 0.f;   // the TOML's `trim = true` carries no fraction (the reference ignores it): given here
 	unsigned long long seed = 0;
 	for (int i = 2; i < argc; i++) {
@@ -35,6 +37,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
 		else if (!std::strcmp(argv[i], "--trim-fraction") && i + 1 < argc) trim_fraction = (float)std::atof(argv[++i]);
 		else if (!std::strcmp(argv[i], "--verbose")) verbose = 1;
+		else if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = std::atoi(argv[++i]);
 	}
 	try {
 		Config config(argv[1]);
@@ -47,6 +50,26 @@ int main(int argc, char** argv)
 		goicp_params_from_config(&config.raw, &p);      // mse_threshold + the [params.rotation] / [params.translation] search ranges
 		p.verbose = verbose;
 		p.trim_fraction = trim_fraction;
+		if (ranks > 1 && config.mode > 2) {
+			// the sharded search: one engine per GPU inside the library, rank 0's engine comes back for the result
+			p.mse_threshold = config.mse_threshold;
+			std::vector<goicp_shard_stats> st((size_t)ranks);
+			goicp_handle h0 = nullptr;
+			check(goicp_register_multi_gpu(&p, &target[0].x, target.size(), &source[0].x, source.size(), ranks, 8, &h0, st.data()));
+			goicp_result r;
+			check(goicp_poll(h0, &r));
+			std::printf("Searching over (%d GPUs)! Best Error: %.7g  (MSE %.7g)\n", ranks, r.best_sse, r.best_sse / (float)source.size());
+			for (int k = 0; k < ranks; k++)
+				std::printf("rank %d: %lld steps, %lld exchanges, %lld pose broadcasts, %lld donations (%lld cubes)\n", k, (long long)st[(size_t)k].steps,
+				            (long long)st[(size_t)k].exchanges, (long long)st[(size_t)k].broadcasts, (long long)st[(size_t)k].donations, (long long)st[(size_t)k].donated_cubes);
+			std::printf("Optimal Rotation Matrix:\n");
+			for (int i = 0; i < 3; i++) std::printf("%12.7f %12.7f %12.7f\n", r.optR[3 * i], r.optR[3 * i + 1], r.optR[3 * i + 2]);
+			std::printf("Optimal Translation Vector:\n%12.7f\n%12.7f\n%12.7f\n", r.optT[0], r.optT[1], r.optT[2]);
+			if (!config.io.output.empty()) check(goicp_result_write_toml(h0, config.io.output.c_str()));
+			if (!config.io.visualization.empty()) check(goicp_result_write_ply(h0, config.io.visualization.c_str()));
+			goicp_destroy(h0);
+			return 0;
+		}
 		std::mutex mtx;
 		icp::FastGoICP engine(target, source, config.mse_threshold, mtx, &p);
 		goicp_handle h = engine.registration.handle();

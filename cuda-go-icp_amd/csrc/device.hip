@@ -18,6 +18,7 @@
 //   nn_query_kernel      1-NN operator for arbitrary queries
 //   dt_*                 exact Euclidean DT build (seed, three separable min-plus passes, sqrt/scale)
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <climits>
 #include <cmath>
 
@@ -47,6 +48,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 // ------------------------------------------------------------------------------------------------
 // DT lookup = DT3D::Distance (jly_3ddt.cpp:981-1026), nearest voxel with int(x+0.5) truncation
 // ------------------------------------------------------------------------------------------------
+// layout 2 (opt-in, Params::bounds_fp16): the bricked grid in IEEE half precision -- a 4x4x4 brick is then ONE 128-byte
+// line instead of two, which halves the distinct lines a 64-lane gather touches (the cost the bounds kernel is bound
+// by).  Values are rounded toward zero when the copy is made, so every lower bound stays a valid lower bound; upper
+// bounds come out low by at most 2^-10 relative.  Index arithmetic is the bricked layout's.
+__device__ __forceinline__ float half_bits_to_float(unsigned short h)
+{
+	return __half2float(__ushort_as_half(h));
+}
+// element e of a half grid through a 4-byte load of the aligned pair that holds it (measured: 2-byte gathers run at a
+// fraction of the dword rate -- the S2 launch took 80.6 ms with global_load_ushort against 53.8 ms in fp32)
+__device__ __forceinline__ float half_fetch(const float* grid, unsigned e)
+{
+	const unsigned w = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(grid) + (size_t)((e >> 1) << 2));
+	return half_bits_to_float((unsigned short)((e & 1u) ? (w >> 16) : (w & 0xffffu)));
+}
+
 template <int LAYOUT>
 __device__ __forceinline__ float dt_fetch(const DtDesc& dt, int x, int y, int z)
 {
@@ -59,6 +76,7 @@ __device__ __forceinline__ float dt_fetch(const DtDesc& dt, int x, int y, int z)
 		const unsigned b = __umul24(__umul24((unsigned)z >> 2, (unsigned)dt.VB) + ((unsigned)y >> 2), (unsigned)dt.VB) + ((unsigned)x >> 2);
 		e = (b << 6) | ((((unsigned)z & 3u) << 4) | (((unsigned)y & 3u) << 2) | ((unsigned)x & 3u));
 	}
+	if (LAYOUT == 2) return half_fetch(dt.grid, e);
 	return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
 }
 
@@ -188,7 +206,10 @@ __device__ __forceinline__ void sibling_residuals(const DtDesc& dt, const Rot9& 
 	for (int c = 0; c < kGroup; c++) {
 		const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
 		float v;
-		if (e < kOutside) v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
+		if (e < kOutside) {
+			if (LAYOUT == 2) v = half_fetch(dt.grid, e);
+			else v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dt.grid) + (size_t)(e << 2));
+		}
 		else v = dt_distance<LAYOUT>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);   // clamp + overshoot extension
 		v = v - rho;
 		m[c] = v < 0.f ? 0.f : v;
@@ -534,6 +555,7 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
 	const dim3 grid((B + kGroup - 1) / kGroup), block(kTrimThreads);
+	if (dt.layout == 2) return hipErrorInvalidValue;          // the trimmed form is evaluated on the fp32 grid
 	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
 	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
 	return hipGetLastError();
@@ -579,13 +601,15 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 	if (inliers < N) {
 		// trimmed form: one workgroup per expansion, the surplus workgroups of the fixed grid leave at once
 		const dim3 grid(max_groups), block(kTrimThreads);
+		if (dt.layout == 2) return hipErrorInvalidValue;
 		if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
 		else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
 		return hipGetLastError();
 	}
 	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
 	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
-	else hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
+	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
+	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
 	hipLaunchKernelGGL(bounds_queue_finalize, dim3(256), dim3(256), 0, stream, scratch, d_groups, N, ub, lb);
 	return hipGetLastError();
 }
@@ -599,8 +623,10 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 	dim3 grid(groups * chunks), block(kBoundsThreads);
 	if (dt.layout == 0)
 		hipLaunchKernelGGL(bounds_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
-	else
+	else if (dt.layout == 1)
 		hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
+	else
+		hipLaunchKernelGGL(bounds_kernel<2>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
 	if (chunks > 1) {
 		int t = groups * 2 * kGroup;
 		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, B, groups, chunks, ub, lb);
@@ -837,10 +863,10 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 
 // Workgroup-shared state of one ICP iteration: the per-wavefront sums of the pass and the finalize's scratch, in ONE
 // __shared__ object (a second one beside it can make the compiler drain the memory pipeline before LDS reads).
-constexpr int kFinThreads = kIcpThreads;           // 256: 64 row streams x four float4 columns
-struct FinScratch { double wsum[kFinThreads / 64][kIcpAcc]; double sums[kIcpAcc]; float red[kIcpThreads / 64][kIcpAcc]; int last; };
-__device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh);
-__device__ void finalize_serial(const double* __restrict__ sums, IcpState* __restrict__ state);
+constexpr int kFinThreads = 1024;                  // the stand-alone finalize: 256 row streams x four float4 columns
+struct FinScratch { double wsum[kFinThreads / 64][kIcpAcc]; double sums[kIcpAcc]; float red[kIcpThreads / 16][kIcpAcc]; int last; };   // red: one row of sums per 16-lane row
+template <int T> __device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh);
+__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, int lane);
 
 // FUSED: the workgroup that arrives last (one ticket per launch; agent-scope release before the ticket, acquire
 // after it -- cdna_hip_programming.md Guideline 16, counter form) also runs the finalize, so an ICP iteration is ONE
@@ -851,7 +877,7 @@ __global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* 
                                                                   float* __restrict__ partials, int* __restrict__ ticket)
 {
 	__shared__ FinScratch sh;
-	float (*red)[kIcpAcc] = sh.red;
+	float (*red)[kIcpAcc] = sh.red;                                   // [16 rows of the workgroup][16 sums]
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
 	const int i = (blockIdx.x * (kIcpThreads / 64) + wave) * 4 + row;
 	const bool valid = i < N;
@@ -876,28 +902,45 @@ __global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* 
 		acc[12] = az * bx; acc[13] = az * by; acc[14] = az * bz;
 		acc[15] = r.best;
 	}
-#pragma unroll
-	for (int k = 0; k < kIcpAcc; k++) {
-		float v = row_sum_f32(acc[k]);                           // fixed butterfly order: deterministic
-		v += __shfl_xor(v, 16, 64);
-		v += __shfl_xor(v, 32, 64);
-		if (lane == 0) red[wave][k] = v;
+	// Exactly one lane of a row holds its correspondence (the others hold zeros), so there is nothing to reduce inside a
+	// row: that lane stores its 16 terms to LDS (four 16-byte stores), rows without a query store zeros, and 16 threads add
+	// the workgroup's 16 rows in fixed order.  (The previous form ran 16 DPP row sums + 32 cross-row shuffles per wavefront:
+	// 160 of the ~1 180 VALU instructions of a wavefront, on a kernel the counters show to be VALU-issue-limited.)
+	{
+		const int wrow = wave * 4 + row;
+		const bool owner = valid ? r.mine : l == 0;
+		if (owner) {
+			float4* dst = reinterpret_cast<float4*>(red[wrow]);
+			dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+			dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+			dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+			dst[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x < kIcpAcc) {
 		float sum = red[0][threadIdx.x];
 #pragma unroll
-		for (int x = 1; x < kIcpThreads / 64; x++) sum += red[x][threadIdx.x];
-		partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = sum;
+		for (int x = 1; x < kIcpThreads / 16; x++) sum += red[x][threadIdx.x];
+		if constexpr (FUSED) {
+			// publish the row WRITE-THROUGH (agent-scope relaxed 8-byte stores = sc1): no release fence, i.e. no L2
+			// write-back per workgroup (measured: with a release fence in each of the 1 899 workgroups the pass took 61 us
+			// instead of 27)
+			const float nb = __shfl_down(sum, 1, 64);
+			if ((threadIdx.x & 1) == 0) {
+				const unsigned long long pk = (unsigned long long)__float_as_uint(sum) | ((unsigned long long)__float_as_uint(nb) << 32);
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(partials + (size_t)blockIdx.x * kIcpAcc + threadIdx.x), pk, __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+			}
+		} else {
+			partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = sum;
+		}
 	}
 	if constexpr (FUSED) {
-		// publish this workgroup's row: stores drained by the storing wave, workgroup barrier, then ONE lane releases
-		// at agent scope and draws the ticket (the explicit waits stay: the compiler may drop the fence's own)
+		// the storing wave drains its stores, workgroup barrier, then ONE lane draws the ticket
 		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const int last = t == (int)gridDim.x - 1;
 			if (last) {
@@ -909,8 +952,8 @@ __global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* 
 		}
 		__syncthreads();
 		if (!sh.last) return;
-		finalize_reduce(partials, (int)gridDim.x, sh);
-		if (threadIdx.x == 0) finalize_serial(sh.sums, st);
+		finalize_reduce<kIcpThreads>(partials, (int)gridDim.x, sh);
+		if (threadIdx.x < 64) finalize_rows(sh.sums, st, (int)threadIdx.x);
 	}
 }
 
@@ -1213,13 +1256,14 @@ __device__ void kabsch_rotation_dev(const double H[9], float R[9])
 // workgroup of the fused iteration kernel and by the stand-alone finalize launch (trimmed ICP, A/B tests):
 // the same code and the same summation order, so both forms give bit-identical states.
 
-// every thread of the workgroup; returns with sh.sums[] valid for all threads
+// every thread of the workgroup (T threads); returns with sh.sums[] valid for all threads
+template <int T>
 __device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh)
 {
 	// A chain of dependent memory round trips (~1-2 us each: the partials were written by other XCDs), so the loads
 	// of a sweep -- eight float4 per thread -- are requested before anything is waited for.  64 row streams x four
 	// float4 columns; fixed-order sums (registers, xor-butterfly inside a wavefront, then the wavefront totals in order).
-	constexpr int kRows = kFinThreads / 4;
+	constexpr int kRows = T / 4;
 	const int q = threadIdx.x & 3, r = threadIdx.x >> 2;
 	const float4* __restrict__ P = reinterpret_cast<const float4*>(partials);
 	double a[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1250,69 +1294,154 @@ __device__ __forceinline__ void finalize_reduce(const float* __restrict__ partia
 	__syncthreads();
 	if (threadIdx.x < kIcpAcc) {
 		double t = 0.0;
-		for (int i = 0; i < kFinThreads / 64; i++) t += sh.wsum[i][threadIdx.x];
+		for (int i = 0; i < T / 64; i++) t += sh.wsum[i][threadIdx.x];
 		sh.sums[threadIdx.x] = t;
 	}
 	__syncthreads();
 }
 
-// one lane: the serial rest of the loop body.  __noinline__: its fp64 working set must not set the register
-// budget of the correspondence pass it is fused into (it is compiled within the caller's launch bounds).
-__device__ __noinline__ void finalize_serial(const double* __restrict__ sums, IcpState* __restrict__ state)
+// ---- the rest of the loop body, three lanes wide ---------------------------------------------------------------
+// Lane i (i = 0, 1, 2 of ONE wavefront; the other lanes idle along) owns coordinate i of every vector and row i of every
+// 3x3 matrix: the means, H, the one-sided Jacobi SVD (rows of B and V rotate independently; the column inner products
+// are three-lane sums taken in the serial order (x0 + x1) + x2), R_ = V diag(1,1,det) U^T, t_, the composed pose.  Same
+// arithmetic as a one-lane version, a third of the dependent fp64 chain, and ~40 registers instead of ~150 -- which is
+// what lets the correspondence pass carry this code without losing occupancy.
+__device__ __forceinline__ double lane_get(double x, int j) { return __shfl(x, j, 64); }
+__device__ __forceinline__ float lane_getf(float x, int j) { return __shfl(x, j, 64); }
+__device__ __forceinline__ double sum3(double x) { return (lane_get(x, 0) + lane_get(x, 1)) + lane_get(x, 2); }
+
+// rows of H in (b0, b1, b2) on lanes 0..2 -> row of the Kabsch rotation in r[3] (same algorithm as kabsch_rotation_dev)
+__device__ __forceinline__ void kabsch_rows(double b0, double b1, double b2, int row, float r[3])
 {
-	IcpState st = *state;
+	double v0 = row == 0 ? 1.0 : 0.0, v1 = row == 1 ? 1.0 : 0.0, v2 = row == 2 ? 1.0 : 0.0;
+#define GOICP_JACOBI(bp, bq, vp, vq)                                                                        \
+	{                                                                                                       \
+		const double app = sum3(bp * bp), aqq = sum3(bq * bq), apq = sum3(bp * bq);                         \
+		if (!(apq == 0.0 || apq * apq <= 1e-24 * (app * aqq))) {                                            \
+			rotated = true;                                                                                 \
+			const double da = aqq - app, db = 2 * apq;                                                      \
+			const double tn = (da >= 0 ? db : -db) / (fabs(da) + sqrt(da * da + db * db));                  \
+			const double cs = rsqrt(1 + tn * tn), sn = cs * tn;                                             \
+			const double nbp = cs * bp - sn * bq, nbq = sn * bp + cs * bq;                                  \
+			const double nvp = cs * vp - sn * vq, nvq = sn * vp + cs * vq;                                  \
+			bp = nbp; bq = nbq; vp = nvp; vq = nvq;                                                         \
+		}                                                                                                   \
+	}
+#pragma unroll 1
+	for (int sweep = 0; sweep < 32; sweep++) {
+		bool rotated = false;
+		GOICP_JACOBI(b0, b1, v0, v1)
+		GOICP_JACOBI(b0, b2, v0, v2)
+		GOICP_JACOBI(b1, b2, v1, v2)
+		if (!rotated) break;
+	}
+#undef GOICP_JACOBI
+	const double n0 = sum3(b0 * b0), n1 = sum3(b1 * b1), n2 = sum3(b2 * b2);
+	const double rn0 = n0 > 0 ? rsqrt(n0) : 0.0, rn1 = n1 > 0 ? rsqrt(n1) : 0.0, rn2 = n2 > 0 ? rsqrt(n2) : 0.0;
+	const double W0 = n0 * rn0, W1 = n1 * rn1, W2 = n2 * rn2;
+	double u0 = b0 * rn0, u1 = b1 * rn1, u2 = b2 * rn2;                       // row `row` of U
+	// rank-2 input: the missing left vector is the cross product of the other two (row i needs rows i+1, i+2)
+	const int ra = (row + 1) % 3, rb = (row + 2) % 3;
+	{
+		const double a1 = lane_get(u1, ra), a2 = lane_get(u2, ra), c1 = lane_get(u1, rb), c2 = lane_get(u2, rb);   // U[ra][1], U[ra][2], U[rb][1], U[rb][2]
+		const double a0 = lane_get(u0, ra), c0 = lane_get(u0, rb);
+		if (!(W0 > 1e-200) && W1 > 1e-200 && W2 > 1e-200) u0 = a1 * c2 - c1 * a2;       // columns a = 1, b = 2
+		if (!(W1 > 1e-200) && W2 > 1e-200 && W0 > 1e-200) u1 = a2 * c0 - c2 * a0;       // columns a = 2, b = 0
+		if (!(W2 > 1e-200) && W0 > 1e-200 && W1 > 1e-200) u2 = a0 * c1 - c0 * a1;       // columns a = 0, b = 1
+	}
+	// VUt[row][j] = sum_k V[row][k] U[j][k]
+	double vut[3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		double t = 0;
+		t += v0 * lane_get(u0, j);
+		t += v1 * lane_get(u1, j);
+		t += v2 * lane_get(u2, j);
+		vut[j] = t;
+	}
+	const double m00 = lane_get(vut[0], 0), m01 = lane_get(vut[1], 0), m02 = lane_get(vut[2], 0);
+	const double m10 = lane_get(vut[0], 1), m11 = lane_get(vut[1], 1), m12 = lane_get(vut[2], 1);
+	const double m20 = lane_get(vut[0], 2), m21 = lane_get(vut[1], 2), m22 = lane_get(vut[2], 2);
+	const double det = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+	// the reference sorts singular values in decreasing order (matrix.cpp:782-808): its diag(1,1,det)
+	// (jly_icp3d.hpp:268-285) corrects the direction of the smallest one
+	int ks = 0;
+	double Wk = W0;
+	if (W1 < Wk) { ks = 1; Wk = W1; }
+	if (W2 < Wk) ks = 2;
+#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		double t = 0;
+		t += v0 * (ks == 0 ? det : 1.0) * lane_get(u0, j);
+		t += v1 * (ks == 1 ? det : 1.0) * lane_get(u1, j);
+		t += v2 * (ks == 2 ? det : 1.0) * lane_get(u2, j);
+		r[j] = (float)t;
+	}
+}
+
+// called by every lane of ONE wavefront (lanes >= 3 shadow lane 2 and write nothing)
+__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, int lane)
+{
+	const int a = lane < 3 ? lane : 2;
+	const bool writer = lane < 3;
 	const float err_new = (float)sums[15];
-	st.err_new = err_new;
-	st.passes += 1;
-	if (st.frozen) { state->err_new = err_new; state->passes = st.passes; return; }   // timing / scoring only
-	if (st.err > 0.f && st.err - err_new < st.err_diff_n) {                  // jly_icp3d.hpp:255
-		state->err_new = err_new; state->passes = st.passes; state->converged = 1;
+	const int passes = state->passes + 1;
+	if (state->frozen) {                                                     // timing / scoring only
+		if (lane == 0) { state->err_new = err_new; state->passes = passes; }
 		return;
 	}
-	st.err = err_new;
-	const double nn = (double)st.n;
-	double alpha[3], beta[3];
-	for (int a = 0; a < 3; a++) {
-		const double sum_q = sums[a] + nn * (double)st.cq[a];
-		const double sum_m = sums[3 + a] + nn * (double)st.cm[a];
-		// jly_icp3d.hpp:244-263: the reference accumulates on top of the previous means and divides by n
-		const double carry_d = st.carry_means ? (double)st.mu_d[a] : 0.0;
-		const double carry_m = st.carry_means ? (double)st.mu_m[a] : 0.0;
-		st.mu_d[a] = (float)((carry_d + sum_q) / nn);
-		st.mu_m[a] = (float)((carry_m + sum_m) / nn);
-		alpha[a] = (double)st.mu_d[a] - (double)st.cq[a];
-		beta[a] = (double)st.mu_m[a] - (double)st.cm[a];
+	const float err = state->err;
+	if (err > 0.f && err - err_new < state->err_diff_n) {                    // jly_icp3d.hpp:255
+		if (lane == 0) { state->err_new = err_new; state->passes = passes; state->converged = 1; }
+		return;
 	}
-	double H[9];
-	for (int i = 0; i < 3; i++)
-		for (int j = 0; j < 3; j++) {
-			const double h = sums[6 + 3 * i + j] - alpha[i] * sums[3 + j] - sums[i] * beta[j] + nn * alpha[i] * beta[j];
-			H[3 * i + j] = (double)(float)h;                                  // the reference holds H in float
-		}
-	float R_[9], t_[3], Rn[9], tn[3];
-	kabsch_rotation_dev(H, R_);
-	for (int i = 0; i < 3; i++) {
-		float acc = 0.f;
-		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.mu_d[a];
-		t_[i] = st.mu_m[i] - acc;                                             // t_ = mu_m - R_ mu_d
+	const double nn = (double)state->n;
+	const float cq = state->cq[a], cm = state->cm[a];
+	const bool carry = state->carry_means != 0;
+	const double sum_q = sums[a] + nn * (double)cq;
+	const double sum_m = sums[3 + a] + nn * (double)cm;
+	// jly_icp3d.hpp:244-263: the reference accumulates on top of the previous means and divides by n
+	const double carry_d = carry ? (double)state->mu_d[a] : 0.0;
+	const double carry_m = carry ? (double)state->mu_m[a] : 0.0;
+	const float mu_d = (float)((carry_d + sum_q) / nn);
+	const float mu_m = (float)((carry_m + sum_m) / nn);
+	const double alpha = (double)mu_d - (double)cq, beta = (double)mu_m - (double)cm;
+	double h[3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		const double hj = sums[6 + 3 * a + j] - alpha * sums[3 + j] - sums[a] * lane_get(beta, j) + nn * alpha * lane_get(beta, j);
+		h[j] = (double)(float)hj;                                            // the reference holds H in float
 	}
-	for (int i = 0; i < 3; i++) {
-		for (int j = 0; j < 3; j++) {
-			float acc = 0.f;
-			for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.R[3 * a + j];
-			Rn[3 * i + j] = acc;                                              // R <- R_ R
-		}
-		float acc = 0.f;
-		for (int a = 0; a < 3; a++) acc += R_[3 * i + a] * st.t[a];
-		tn[i] = acc + t_[i];                                                  // t <- R_ t + t_
+	float Rrow[3];
+	kabsch_rows(h[0], h[1], h[2], a, Rrow);
+	float oldR[9], oldt[3], sc[3];
+#pragma unroll
+	for (int k = 0; k < 9; k++) oldR[k] = state->R[k];
+#pragma unroll
+	for (int k = 0; k < 3; k++) { oldt[k] = state->t[k]; sc[k] = state->src_centroid[k]; }
+	float acc = 0.f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) acc += Rrow[k] * lane_getf(mu_d, k);
+	const float t_ = mu_m - acc;                                             // t_ = mu_m - R_ mu_d
+	float Rn[3];
+#pragma unroll
+	for (int j = 0; j < 3; j++) {
+		float s2 = 0.f;
+#pragma unroll
+		for (int k = 0; k < 3; k++) s2 += Rrow[k] * oldR[3 * k + j];
+		Rn[j] = s2;                                                          // R <- R_ R
 	}
-	for (int i = 0; i < 9; i++) st.R[i] = Rn[i];
-	for (int i = 0; i < 3; i++) {
-		st.t[i] = tn[i];
-		st.cq[i] = Rn[3 * i] * st.src_centroid[0] + Rn[3 * i + 1] * st.src_centroid[1] + Rn[3 * i + 2] * st.src_centroid[2] + tn[i];
+	float s3 = 0.f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) s3 += Rrow[k] * oldt[k];
+	const float tn = s3 + t_;                                                // t <- R_ t + t_
+	const float cq_new = Rn[0] * sc[0] + Rn[1] * sc[1] + Rn[2] * sc[2] + tn;
+	const int iters = state->iters + 1;
+	if (writer) {
+		state->R[3 * a] = Rn[0]; state->R[3 * a + 1] = Rn[1]; state->R[3 * a + 2] = Rn[2];
+		state->t[a] = tn; state->cq[a] = cq_new; state->mu_d[a] = mu_d; state->mu_m[a] = mu_m;
 	}
-	st.iters += 1;
-	*state = st;
+	if (lane == 0) { state->err = err_new; state->err_new = err_new; state->passes = passes; state->iters = iters; }
 }
 
 __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
@@ -1320,8 +1449,8 @@ __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* 
 {
 	__shared__ FinScratch sh;
 	if (state->converged) return;                 // uniform; the pass kernel left the partials untouched
-	finalize_reduce(partials, nblocks, sh);
-	if (threadIdx.x == 0) finalize_serial(sh.sums, state);
+	finalize_reduce<kFinThreads>(partials, nblocks, sh);
+	if (threadIdx.x < 64) finalize_rows(sh.sums, state, (int)threadIdx.x);
 }
 
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
@@ -1362,13 +1491,15 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const float* __restri
 	const unsigned mask = window - 1u;
 	unsigned h = __builtin_amdgcn_readfirstlane(wave * 2654435761u + 12345u);
 	float acc = 0.f;
-	const unsigned mine = MODE == 0 ? lane : lane * 32u;
+	// MODE 0: 64 consecutive floats; MODE 1: 64 lines; MODE k >= 2: k distinct 128-byte lines per instruction, the lanes in
+	// k runs of 64/k consecutive floats (lines 8 apart so that neighbouring runs never share a line)
+	const unsigned mine = MODE == 0 ? lane : (MODE == 1 ? lane * 32u : (lane / (64u / MODE)) * 256u + (lane % (64u / MODE)));
 	for (int it = 0; it < iters; it++) {
 		float v[8];
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
 			h = h * 1664525u + 1013904223u;
-			const unsigned base = MODE == 0 ? ((h >> 7) & mask & ~63u) : ((h >> 7) & mask);
+			const unsigned base = MODE == 1 ? ((h >> 7) & mask) : ((h >> 7) & mask & ~31u);
 			v[u] = w[(base + mine) & mask];
 		}
 #pragma unroll
@@ -1381,8 +1512,15 @@ hipError_t launch_probe_gather(const DtDesc& dt, int mode, unsigned window, int 
 {
 	const unsigned n = dt.layout ? (unsigned)dt.VB * dt.VB * dt.VB * 64u : (unsigned)dt.V * dt.V * dt.V;
 	if (window < 4096u || (window & (window - 1u)) || window > n) return hipErrorInvalidValue;
-	if (mode == 0) hipLaunchKernelGGL(probe_gather_kernel<0>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink);
-	else hipLaunchKernelGGL(probe_gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink);
+	switch (mode) {
+	case 0: hipLaunchKernelGGL(probe_gather_kernel<0>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	case 1: hipLaunchKernelGGL(probe_gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	case 4: hipLaunchKernelGGL(probe_gather_kernel<4>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	case 8: hipLaunchKernelGGL(probe_gather_kernel<8>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	case 16: hipLaunchKernelGGL(probe_gather_kernel<16>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	case 32: hipLaunchKernelGGL(probe_gather_kernel<32>, dim3(blocks), dim3(256), 0, stream, dt.grid, n, window, iters, sink); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 
@@ -1556,6 +1694,18 @@ __global__ void dt_finish_kernel(const int32_t* w, DtDesc dt, float* out)
 		size_t b = ((size_t)(z >> 2) * dt.VB + (y >> 2)) * dt.VB + (x >> 2);
 		out[b * 64 + (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))] = v;
 	}
+}
+
+// half-precision copy of a bricked grid, rounded toward zero (|half| <= |float|: lower bounds stay valid)
+__global__ void dt_to_half_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = __half_as_ushort(__float2half_rz(in[i]));
+}
+hipError_t launch_dt_to_half(const float* bricked, void* out_half, size_t n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(dt_to_half_kernel, dim3(4096), dim3(256), 0, stream, bricked, static_cast<unsigned short*>(out_half), n);
+	return hipGetLastError();
 }
 
 hipError_t launch_dt_build(const float* model_xyz, int M, const DtDesc& dt, int32_t* work, float* out, hipStream_t stream)

@@ -11,6 +11,7 @@ namespace goicp {
 //   layout 0: linear  [z][y][x], x fastest                       (reference order, jly_3ddt.h:53-79)
 //   layout 1: bricked 4x4x4 voxels per 256-B brick, bricks [bz][by][bx]; a surface patch touched
 //             by one wavefront then spans ~4x fewer cache lines than in the linear layout
+//   layout 2: the bricked grid in half precision (128-B bricks), rounded toward zero; bounds evaluation only, opt-in
 struct DtDesc {
 	const float* grid;
 	int V;          // voxels per side
@@ -159,5 +160,6 @@ hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], 
 // work: V^3 int32 (linear).  out: V^3 floats in dt.layout (may alias work only for layout 0).
 hipError_t launch_dt_build(const float* model_xyz, int M, const DtDesc& dt, int32_t* work, float* out,
                            hipStream_t stream);
+hipError_t launch_dt_to_half(const float* bricked, void* out_half, size_t n, hipStream_t stream);
 
 }  // namespace goicp

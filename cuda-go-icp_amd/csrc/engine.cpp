@@ -346,6 +346,13 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			dt_.overshoot = d_overshoot_; dt_.n_overshoot = n;
 		}
 		HIPCHK(launch_dt_build(d_model, (int)M_, dt_, d_work, d_dt_, stream_));
+		if (p_.bounds_fp16 && dt_.layout == 1) {
+			HIPCHK(hipMalloc(&d_dt16_, sizeof(unsigned short) * nout));
+			HIPCHK(launch_dt_to_half(d_dt_, d_dt16_, nout, stream_));
+			dt16_ = dt_;
+			dt16_.grid = static_cast<const float*>(d_dt16_);
+			dt16_.layout = 2;
+		}
 		HIPCHK(hipStreamSynchronize(stream_));
 		dt_build_ms_ = now_ms() - t0;
 	}
@@ -438,7 +445,7 @@ void Engine::release()
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
-	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_);
+	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_); hipFree(d_dt16_); d_dt16_ = nullptr;
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
@@ -521,7 +528,7 @@ void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, 
 	if (inliers_ < (int)N_)
 		HIPCHK(launch_bounds_trim(d_src_, (int)N_, dt_, d_rots, d_cubes, d_parents, B, inliers_, d_ub, d_lb, s ? s : stream_));
 	else
-		HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rots, d_cubes, d_parents, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
+		HIPCHK(launch_bounds(d_src_, (int)N_, bounds_dt(), d_rots, d_cubes, d_parents, B, d_scratch_, d_ub, d_lb, s ? s : stream_));
 	cnt_.bounds_launches++;
 }
 
@@ -580,6 +587,7 @@ float Engine::eval_sse(const float R[9], const float t[3])
 	// sum_i Distance(R p_i + t)^2 (jly_goicp.cpp:100-129): one cube with centre t, no radii
 	float cube[4] = {t[0], t[1], t[2], 0.f};
 	float ub = 0.f, lb = 0.f;
+	struct Exact { bool& f; explicit Exact(bool& x) : f(x) { f = true; } ~Exact() { f = false; } } exact(score_exact_);   // a score, not a bound: fp32 grid
 	eval_bounds(R, cube, 1, -1, &ub, &lb);
 	cnt_.cubes -= 1;   // a score, not a BnB cube bound
 	return ub;
@@ -723,6 +731,7 @@ double Engine::probe_gather(int mode, size_t window_bytes)
 	while ((size_t)window * 4 < window_bytes && window < (1u << 30)) window <<= 1;
 	const size_t nfl = dt_.layout ? (size_t)dt_.VB * dt_.VB * dt_.VB * 64 : (size_t)dt_.V * dt_.V * dt_.V;
 	while ((size_t)window > nfl) window >>= 1;
+	if (mode >= 2 && window < 16384u) window = 16384u;          // k runs 256 floats apart need 64 KiB
 	int cus = 256;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, dev_) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
@@ -845,7 +854,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		int last = 0;
 		for (int r = 0; r < chunk; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qctl_, parity, stream_));
-			HIPCHK(launch_bounds_queue(d_src_, (int)N_, dt_, d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], max_groups,
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], max_groups,
 			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
 			last = parity;
 			parity ^= 1;

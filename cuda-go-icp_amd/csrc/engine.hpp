@@ -29,6 +29,7 @@ struct Params {
 	int morton_sort = 2;          // source order on the device: 0 input order, 1 Morton curve, 2 k-d order (locality of the DT gathers)
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
+	int bounds_fp16 = 0;          // 1: BnB cube bounds read a half-precision copy of the bricked DT (rounded toward zero: lower bounds stay valid, upper bounds low by <= 2^-10 relative); ICP, the DT re-score and trimmed bounds keep the fp32 grid.  Not bit-parity: opt-in
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -178,6 +179,10 @@ private:
 	float src_centroid_[3] = {0, 0, 0}, model_centroid_[3] = {0, 0, 0};
 	DtDesc dt_{};
 	float* d_dt_ = nullptr;
+	DtDesc dt16_{};                   // Params::bounds_fp16: the same grid in half precision (layout 2)
+	void* d_dt16_ = nullptr;
+	bool score_exact_ = false;        // set while eval_sse scores a pose: always the fp32 grid
+	const DtDesc& bounds_dt() const { return (d_dt16_ && !score_exact_ && inliers_ >= (int)N_) ? dt16_ : dt_; }
 	double* d_overshoot_ = nullptr;
 	// k-d tree
 	KdDesc kd_{};

@@ -112,7 +112,7 @@ void goicp_params_default(goicp_params* p)
 		p->trans_min[k] = d.trans_min[k]; p->trans_max[k] = d.trans_max[k];
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
-	p->icp_fused = d.icp_fused; p->device_queues = d.device_queues;
+	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->device_queues = d.device_queues;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -155,7 +155,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 				p.trans_min[k] = params->trans_min[k]; p.trans_max[k] = params->trans_max[k];
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
-			p.icp_fused = params->icp_fused; p.device_queues = params->device_queues;
+			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.device_queues = params->device_queues;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }
@@ -199,7 +199,7 @@ int goicp_set_progress_callback(goicp_handle h, goicp_progress_fn cb, void* user
 
 int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s)
 {
-	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1));
+	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1 || mode == 4 || mode == 8 || mode == 16 || mode == 32));
 	return guarded([&] { *lookups_per_s = h->e->probe_gather(mode, window_bytes); });
 }
 

@@ -1,0 +1,177 @@
+// Sanitizer driver for the HOST side of libgoicp_mi355 (make -C cuda-go-icp_amd/csrc asan | tsan).  No HIP call
+// is made: it links only the translation units that are pure host code -- the sharding protocol and its in-process
+// communicator (shard.cpp), the threaded k-d build (kdtree.cpp: parallel_tasks), the TOML / PLY / TXT readers and
+// the result writers (config_io.cpp) -- and drives them from several threads.  Run on the CPU only, never on the GPU box.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <queue>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/goicp_mi355.h"
+#include "config_io.hpp"
+#include "engine.hpp"
+
+namespace goicp {
+int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, int rot_pops_per_step, int rebalance, goicp_shard_stats* stats);
+int thread_comm_create(int world, goicp_comm_ops* out);
+void thread_comm_destroy(goicp_comm_ops* comm);
+}  // namespace goicp
+
+namespace {
+
+int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "host selftest: %s failed (line %d)\n", #c, __LINE__); g_fail++; } } while (0)
+
+// A toy engine with the stepped interface: "cubes" are integers with a fixed pseudo-random lower bound and a leaf value;
+// popping a cube may improve the incumbent and spawns two children.  Deterministic, so the sharded runs must all reach
+// the same best value as a single rank.
+struct ToyEngine {
+	struct Cube { float lb; int id, depth; bool operator<(const Cube& o) const { return lb > o.lb; } };
+	std::priority_queue<Cube> q;
+	float best = 1e9f, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+	int rank = 0, world = 1;
+	long long pops = 0;
+	static float value(int id) { return 10.f + (float)((unsigned)(id * 2654435761u) >> 20) * 1e-3f; }
+	static float bound(int id, int depth) { return value(id) - 8.f / (float)(1 + depth); }
+	void begin(int r, int w)
+	{
+		rank = r; world = w; best = 1e9f; pops = 0;
+		while (!q.empty()) q.pop();
+		for (int k = 0; k < 64; k++) if (k % w == r) q.push(Cube{bound(1000 + k, 2), 1000 + k, 2});
+	}
+	void step(int max_pops, goicp_step_status* s)
+	{
+		int n = 0;
+		while (!q.empty() && n < max_pops) {
+			Cube c = q.top(); q.pop(); n++; pops++;
+			if (best - c.lb <= 0.01f) { while (!q.empty()) q.pop(); break; }
+			if (value(c.id) < best) { best = value(c.id); t[0] = (float)c.id; }
+			if (c.depth < 9)
+				for (int k = 0; k < 2; k++) {
+					const int id = c.id * 2 + k;
+					if (bound(id, c.depth + 1) < best) q.push(Cube{bound(id, c.depth + 1), id, c.depth + 1});
+				}
+		}
+		s->finished = q.empty(); s->early_exit = 0; s->best_sse = best;
+		s->frontier_lb = q.empty() ? INFINITY : q.top().lb; s->rot_pops = pops;
+	}
+};
+int te_begin(void* c, int32_t r, int32_t w) { static_cast<ToyEngine*>(c)->begin(r, w); return 0; }
+int te_step(void* c, int32_t m, goicp_step_status* s) { static_cast<ToyEngine*>(c)->step(m, s); return 0; }
+int te_pose(void* c, float* sse, float R[9], float t[3])
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	*sse = e->best; std::memcpy(R, e->R, sizeof(e->R)); std::memcpy(t, e->t, sizeof(e->t));
+	return 0;
+}
+int te_offer(void* c, float sse, const float*, const float t[3])
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	if (sse < e->best) { e->best = sse; std::memcpy(e->t, t, sizeof(e->t)); }
+	return 0;
+}
+int te_qsize(void* c, int32_t* n) { *n = (int32_t)static_cast<ToyEngine*>(c)->q.size(); return 0; }
+int te_donate(void* c, int32_t max_nodes, float* nodes7, int32_t* n)
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	std::vector<ToyEngine::Cube> all;
+	while (!e->q.empty()) { all.push_back(e->q.top()); e->q.pop(); }
+	*n = 0;
+	for (size_t i = 0; i < all.size(); i++) {
+		if ((i & 1) && *n < max_nodes) { float* o = nodes7 + 7 * (*n)++; o[0] = (float)all[i].id; o[5] = all[i].lb; o[6] = (float)all[i].depth; o[1] = o[2] = o[3] = o[4] = 0.f; }
+		else e->q.push(all[i]);
+	}
+	return 0;
+}
+int te_receive(void* c, const float* nodes7, int32_t n)
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	for (int i = 0; i < n; i++) e->q.push(ToyEngine::Cube{nodes7[7 * i + 5], (int)nodes7[7 * i], (int)nodes7[7 * i + 6]});
+	return 0;
+}
+int te_end(void*) { return 0; }
+
+float run_world(int world, int rebalance, long long* donations)
+{
+	std::vector<ToyEngine> eng((size_t)world);
+	std::vector<goicp_comm_ops> comm((size_t)world);
+	CHECK(goicp::thread_comm_create(world, comm.data()) == GOICP_OK);
+	std::vector<goicp_shard_stats> st((size_t)world);
+	std::vector<std::thread> th;
+	for (int r = 0; r < world; r++)
+		th.emplace_back([&, r] {
+			goicp_shard_engine_ops eo{};
+			eo.ctx = &eng[(size_t)r]; eo.sse_threshold = 0.01f;
+			eo.begin = te_begin; eo.step = te_step; eo.pose = te_pose; eo.offer = te_offer; eo.queue_size = te_qsize;
+			eo.donate = te_donate; eo.receive = te_receive; eo.end = te_end;
+			CHECK(goicp::run_sharded(&eo, &comm[(size_t)r], 3, rebalance, &st[(size_t)r]) == GOICP_OK);
+		});
+	for (auto& t : th) t.join();
+	for (int r = 0; r < world; r++) {
+		CHECK(eng[(size_t)r].best == eng[0].best);
+		CHECK(st[(size_t)r].exchanges == st[0].exchanges && st[(size_t)r].broadcasts == st[0].broadcasts);
+		goicp::thread_comm_destroy(&comm[(size_t)r]);
+	}
+	if (donations) *donations = st[0].donations;
+	return eng[0].best;
+}
+
+}  // namespace
+
+int main()
+{
+	// ---- sharding protocol + thread communicator, 1 / 2 / 4 / 7 ranks ----
+	long long don = 0;
+	const float single = run_world(1, 1, nullptr);
+	for (int w : {2, 4, 7}) {
+		const float b = run_world(w, 1, &don);
+		CHECK(std::fabs(b - single) <= 0.01f);
+	}
+	CHECK(std::fabs(run_world(4, 0, &don) - single) <= 0.01f && don == 0);
+	// ---- threaded k-d build ----
+	{
+		std::mt19937 rng(7);
+		std::uniform_real_distribution<float> u(-1.f, 1.f);
+		std::vector<float> pts(3 * 20000);
+		for (float& x : pts) x = u(rng);
+		goicp::KdHost kh;
+		goicp::build_kdtree(pts.data(), 20000, goicp::kLeafSlots, &kh);
+		CHECK(kh.K >= 1 && !kh.pts.empty());
+		size_t real = 0;
+		for (const float4& p : kh.pts) if (std::isfinite(p.x)) real++;
+		CHECK(real == 20000);
+		std::atomic<int> hits{0};
+		goicp::parallel_tasks(8, 100, [&](int) { hits++; });
+		CHECK(hits == 100);
+		float R[9];
+		goicp::rodrigues(0.3f, -0.2f, 0.9f, R);
+		CHECK(std::fabs(R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]) - 1.f) < 1e-5f);
+	}
+	// ---- config / cloud IO ----
+	{
+		const char* toml = "/tmp/goicp_selftest.toml";
+		const char* txt = "/tmp/goicp_selftest.txt";
+		{ std::ofstream f(txt); f << "3\n0 0 0\n1 2 3\n-1 0.5 2\n"; }
+		{ std::ofstream f(toml); f << "[info]\ndescription = \"x\"\n[io]\ntarget = \"" << txt << "\"\nsource = \"" << txt << "\"\n[params]\nmode = 4\nmse_threshold = 1e-3\n[params.rotation]\nxmin = -90\nxmax = 90\n"; }
+		goicp_config c;
+		goicp::load_config(toml, &c);
+		CHECK(c.mode == 4 && c.has_rotation_range == 1 && c.has_translation_range == 0 && c.rot_min[0] == -90.f);
+		std::vector<float> cloud;
+		goicp::load_cloud(txt, 1.0f, 2.0f, 1, cloud);
+		CHECK(cloud.size() == 9 && cloud[3] == 2.f);
+		bool threw = false;
+		try { goicp::load_cloud("/tmp/does_not_exist.ply", 1.f, 1.f, 1, cloud); } catch (const goicp::IoError&) { threw = true; }
+		CHECK(threw);
+		goicp::write_viz_ply("/tmp/goicp_selftest.ply", cloud.data(), 3, cloud.data(), 3);
+		std::vector<float> back;
+		goicp::load_cloud("/tmp/goicp_selftest.ply", 1.f, 1.f, 1, back);
+		CHECK(back.size() == 18);
+	}
+	std::printf("host selftest: %s\n", g_fail ? "FAILED" : "ok");
+	return g_fail ? 1 : 0;
+}

@@ -114,6 +114,10 @@ typedef struct goicp_params {
 	int32_t rot_search_depth, trans_search_depth;
 	int32_t icp_fused;       /* 1: one launch per ICP iteration, the last workgroup to arrive runs the update;
 	                          * 0: correspondence pass + update as two launches (same arithmetic, bit-identical states) */
+	int32_t bounds_fp16;     /* 1: the BnB cube bounds read a half-precision copy of the bricked DT (one 128-byte line per 4x4x4 brick
+	                          * instead of two), rounded toward zero so that lower bounds stay valid; upper bounds come out low by
+	                          * <= 2^-10 relative.  ICP, the DT re-score of a pose and trimmed bounds keep the fp32 grid.  NOT the
+	                          * bit-parity path: opt-in, default 0 */
 	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner
 	                          * searches is two launches, no host round trip; 0: host-side queues (always used with trans_batch == 1,
 	                          * the reference visit order) */
@@ -305,7 +309,8 @@ int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz
 /* ---- measurement / test helpers ----------------------------------------------------------------
  * goicp_probe_gather: measured ceiling of the path that bounds the cube-bound kernel -- independent 4-byte loads
  * into the engine's resident distance transform, nothing else.  mode 0: the 64 lanes of a wave-instruction read 64
- * consecutive floats; mode 1: 64 different 128-byte lines.  window_bytes = footprint each workgroup draws its
+ * consecutive floats; mode 1: 64 different 128-byte lines; mode k in {4, 8, 16, 32}: k distinct lines per instruction, the
+ * lanes in k runs of 64/k consecutive floats (the cost curve between the two extremes).  window_bytes = footprint each workgroup draws its
  * addresses from (rounded up to a power of two, at least 16 KiB, at most the grid).  Result: lookups per second.
  * goicp_debug_kabsch: the device-side 3x3 SVD / Kabsch routine of the ICP update (Matrix::svd use in
  * src/goicp/jly_icp3d.hpp:266-285) on a caller-supplied H (row-major), on the current device; test-only. */

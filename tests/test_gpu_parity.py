@@ -926,3 +926,96 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
     assert a.counters.bounds_launches > 0
     for r in (dev, host, a.registration, b.registration):
         r.close()
+
+
+def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
+    """SURVEY 8(e) with the protocol inside the library (csrc/shard.cpp through goicp_register_sharded): (i) RCCL at
+    world 1 -- ncclAllReduce(MIN) of the packed words and ncclBroadcast really execute on this GPU (a one-GPU box cannot
+    host a second RCCL rank); (ii) 2 and 4 engines on this GPU, one host thread each, over the in-process communicator:
+    the rotation cubes are dealt to the ranks, idle ranks are refilled (rebalancing), every rank ends with the global
+    best, and the optimum is the single-engine one."""
+    import ctypes as C
+    import threading
+    from cuda_go_icp_amd import sharded
+    B = pkg.binding
+    lib = pkg.load_library()
+    g = golden("e2e_bunny10")
+    # (i) RCCL, world 1
+    ident = C.create_string_buffer(128)
+    B.check(lib.goicp_rccl_unique_id(ident))
+    comm = B.CCommOps()
+    B.check(lib.goicp_rccl_comm_create(ident, 0, 1, 0, C.byref(comm)))
+    words = (C.c_uint64 * 3)(5, 1 << 40, 7)
+    assert comm.allreduce_min_u64(comm.ctx, words, 3) == 0 and list(words) == [5, 1 << 40, 7]
+    buf = (C.c_float * 12)(*range(12))
+    assert comm.bcast(comm.ctx, C.cast(buf, C.c_void_p), 48, 0) == 0 and list(buf) == list(map(float, range(12)))
+    eng = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"])
+    st = sharded.run_sharded_library(eng, comm, rot_pops_per_step=8)
+    assert st["exchanges"] >= 1 and st["broadcasts"] >= 1 and eng.finished
+    assert eng.get_best_error() <= 1.02 * g["sse"] and eng.get_best_error() < g["sse_threshold"]
+    assert rot_angle(eng.optR, np.array(g["R"])) <= 3e-2
+    B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
+    eng.registration.close()
+    # the single-process multi-GPU driver behind `goicp_cli --ranks N` (ncclCommInitAll + one host thread per GPU), N = 1 here
+    h0, st1 = C.c_void_p(), B.CShardStats()
+    p = B.CParams()
+    lib.goicp_params_default(C.byref(p))
+    p.mse_threshold = g["mse_threshold"]
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    B.check(lib.goicp_register_multi_gpu(C.byref(p), fp(bunny_model), len(bunny_model), fp(bunny_data10), len(bunny_data10), 1, 8, C.byref(h0), C.byref(st1)))
+    res = B.CResult()
+    B.check(lib.goicp_poll(h0, C.byref(res)))
+    assert res.finished and res.best_sse <= 1.02 * g["sse"] and st1.exchanges >= 1
+    lib.goicp_destroy(h0)
+    # (ii) thread ranks on one GPU
+    for world in (2, 4):
+        engines = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"]) for _ in range(world)]
+        comms = sharded.thread_comms(world)
+        stats, errs = [None] * world, []
+
+        def worker(r):
+            try:
+                stats[r] = sharded.run_sharded_library(engines[r], comms[r], rot_pops_per_step=4)
+            except Exception as e:       # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        best = [float(e.get_best_error()) for e in engines]
+        assert max(best) == min(best)
+        assert best[0] <= 1.02 * g["sse"] and best[0] < g["sse_threshold"]
+        assert all(rot_angle(e.optR, np.array(g["R"])) <= 3e-2 for e in engines)
+        assert len({(s["exchanges"], s["broadcasts"], s["donations"]) for s in stats}) == 1
+        for r in range(world):
+            lib.goicp_thread_comm_destroy(comms[r])
+        for e in engines:
+            e.registration.close()
+
+
+def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
+    """Params::bounds_fp16 (opt-in, not the parity path): the BnB bounds read a half-precision copy of the bricked DT
+    rounded toward zero.  Against the fp32 engine on the same cubes: every lower bound is <= the fp32 one (still a valid
+    lower bound), upper bounds are low by at most 2 x 2^-10 relative (squares), the DT re-score of a pose stays
+    bit-identical (fp32 grid), and a registration reaches the same optimum."""
+    a = pkg.Registration(bunny_model, bunny_data10, 1e-3)
+    b = pkg.Registration(bunny_model, bunny_data10, 1e-3, bounds_fp16=1)
+    rng = np.random.default_rng(5)
+    cubes = _cubes(rng, 256)
+    R = pkg.fgoicp.rodrigues([0.3, -0.2, 0.9])
+    for level in (-1, 4):
+        ua, la = a.eval_bounds(R, cubes, level)
+        ub, lb = b.eval_bounds(R, cubes, level)
+        assert np.all(ub <= ua * (1 + 1e-6)) and np.all(ub >= ua * (1 - 1e-2))      # (v - rho) amplifies the 2^-10 of a half
+        assert np.all(lb <= la * (1 + 1e-6) + 1e-7)
+        assert not np.array_equal(ua, ub)                      # the half grid really is in use
+    t = np.array([0.05, -0.02, 0.01], np.float32)
+    assert a.compute_sse_error(R, t) == b.compute_sse_error(R, t)
+    a.close(); b.close()
+    g = golden("e2e_bunny10")
+    e = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], bounds_fp16=1)
+    e.run()
+    assert e.get_best_error() <= 1.02 * g["sse"] and e.get_best_error() < g["sse_threshold"]
+    assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2
+    e.registration.close()

@@ -225,3 +225,19 @@ int main() {
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+# ----------------------------------------------------------------------------------------------
+# sanitizer builds: CPU only
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("where,target", [("oracle", "asan"), (os.path.join("cuda-go-icp_amd", "csrc"), "asan"),
+                                          (os.path.join("cuda-go-icp_amd", "csrc"), "tsan")])
+def test_sanitizer_targets(where, target):
+    """`make asan` (AddressSanitizer + UBSan) on the oracle and on the library's host-only translation units (sharding
+    protocol + in-process communicator, threaded k-d build, TOML/PLY/TXT IO), `make tsan` (ThreadSanitizer) on the
+    latter: several ranks as host threads through csrc/shard.cpp.  Never run on the GPU box."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, where), target], capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and "unexpected memory mapping" in (r.stdout + r.stderr):
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this sandbox")
+    assert r.returncode == 0 and "selftest: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -246,6 +246,22 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     value = world * Bc * args.steps / elapsed
+    # run-to-run spread: four more timed regions of the same K steps (reported beside `value`, never instead of it)
+    repeats = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tr0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        er = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(er, op=dist.ReduceOp.MAX)
+        repeats.append(world * Bc * args.steps / float(er.item()))
 
     # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the
     # best error + winner's pose between steps) on a noisy synthetic pair -- BASELINE configs[3]'s
@@ -319,8 +335,15 @@ def main():
                "icp_pass_algorithmic_GBs": round(nn_gbs, 1), "icp_bytes_per_iter": icp_bytes,
                "roofline_nn": {"bound": "hbm", "kernel": "goicp::icp_pass_kernel + icp_finalize_update", "achieved": round(nn_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                               "limiter": "latency: the dependent seed -> group -> leaf loads of the slowest wavefront (DESIGN 3.2)"},
+                               "limiter": "not bytes: the dependent seed -> group -> leaf round trips of a walk and VALU issue (DESIGN 3.2)"},
                "pose": "ICP-only local minimum reached from identity (205 forced iterations)"}
+        pmc_icp = os.path.join(ROOT, "profiles", "r02_pmc_icp.json")
+        if args.workload == "bunny" and os.path.exists(pmc_icp):
+            with open(pmc_icp) as f:
+                pj = json.load(f)
+            tr = pj["hbm_bytes_per_pass_corrected"]
+            icp["roofline_nn"].update({"traffic": tr, "traffic_source": "profiles/r02_pmc_icp.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per pass, fabric side of L2)",
+                                       "hbm_frac": round(tr / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "pmc_reading": pj.get("reading")})
 
     out = None
     if rank == 0:
@@ -377,19 +400,29 @@ def main():
                     "launch_ms": round(ms.value, 4), "lookups_per_launch": lookups,
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_launch_as_built": built_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / launch_s, 1)}
+        roofline["frac_of_lines16_l1_probe"] = round(glook / probe.get("lines16_l1", float("nan")), 4)
         if limiter:
             roofline["limiter"] = limiter
+        if args.workload == "s2" and traffic is not None:
+            # BASELINE configs[4] is the HBM-roofline configuration: the 537 MB DT does not fit the Infinity Cache, half of the L2
+            # lookups miss, and the bytes that cross the fabric per launch (PMC) over the launch time ARE the bound here
+            roofline = dict(roofline, bound="hbm", achieved=round(traffic / launch_s / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                            peak_source="MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)",
+                            l1_gather={"achieved_Glookup_per_s": round(glook, 2), "peak": peak, "frac": round(glook / peak, 4) if probe else None})
         # ---- the generic path: SURVEY 8(d)'s batch of unrelated cubes through the same entry point ----
-        g_rots, g_recs, g_nlb = make_generic_batch(pkg, reg, Bc if not args.no_probe else 8, 8, seed=99)
-        gd_rots = torch.from_numpy(g_rots.reshape(-1)).to(dev)
-        gd_cubes = torch.from_numpy(g_recs.view(np.uint8).reshape(-1)).to(dev)
-        gms = C.c_float()
-        B.check(lib.goicp_time_bounds_device(h, gd_rots.data_ptr(), gd_cubes.data_ptr(), len(g_recs), d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(gms)))
-        generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
-                   "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
-                   "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}
-        B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))   # restore the headline batch's outputs
-        torch.cuda.synchronize()
+        generic = None
+        if not args.no_probe:
+            g_rots, g_recs, g_nlb = make_generic_batch(pkg, reg, Bc, 8, seed=99)
+            gd_rots = torch.from_numpy(g_rots.reshape(-1)).to(dev)
+            gd_cubes = torch.from_numpy(g_recs.view(np.uint8).reshape(-1)).to(dev)
+            gms = C.c_float()
+            B.check(lib.goicp_time_bounds_device(h, gd_rots.data_ptr(), gd_cubes.data_ptr(), len(g_recs), d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(gms)))
+            generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
+                       "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
+                       "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}
+            B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))   # restore the headline batch's outputs
+            torch.cuda.synchronize()
         # ---- what this GPU's HBM actually streams (device-to-device copy of 2 GiB, read + write counted) ----
         a_ = torch.empty(1 << 29, dtype=torch.float32, device=dev); b_ = torch.empty_like(a_)
         b_.copy_(a_); torch.cuda.synchronize()
@@ -451,6 +484,8 @@ def main():
                "config": {"workload": "%s: N=%d source, M=%d target, DT %d^3, subsample 1.0" % (wname, N, M, V),
                           "cubes_per_step_per_gpu": Bc, "lb_pass_fraction": n_lb / Bc, "rotations_per_step": 8,
                           "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) best ub" if world > 1 else "local min"},
+               "value_repeats": {"n": len(repeats), "min": round(min(repeats), 1), "max": round(max(repeats), 1),
+                                 "spread_pct": round(100 * (max(repeats) - min(repeats)) / value, 2)},
                "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": sharded_res}
         print(json.dumps(out), flush=True)
     reg.close()

@@ -384,18 +384,19 @@ void write_viz_ply(const std::string& path, const float* target, size_t nt, cons
 	std::fclose(f);
 }
 
-void write_result_toml(const std::string& path, const Result& r, size_t n_source, size_t n_target, float sse_threshold)
+void write_result_toml(const std::string& path, const Result& r, size_t n_source, size_t n_target, float sse_threshold, int inliers)
 {
+	const size_t n_used = inliers > 0 ? (size_t)inliers : n_source;      // the sums run over inlierNum points (jly_goicp.cpp:198-208)
 	FILE* f = std::fopen(path.c_str(), "w");
 	if (!f) throw IoError("cannot write " + path);
 	std::fprintf(f, "# Go-ICP registration result (output promised by the reference configs, test/bunny_goicp.toml:12)\n");
 	std::fprintf(f, "[result]\nfinished = %s\n", r.finished ? "true" : "false");
-	std::fprintf(f, "sse = %.9g\nmse = %.9g\nsse_threshold = %.9g\n", r.best_sse, r.best_sse / (float)n_source, sse_threshold);
+	std::fprintf(f, "sse = %.9g\nmse = %.9g\nsse_threshold = %.9g\n", r.best_sse, r.best_sse / (float)n_used, sse_threshold);
 	std::fprintf(f, "rotation = [\n");
 	for (int i = 0; i < 3; i++)
 		std::fprintf(f, "  [%.9g, %.9g, %.9g]%s\n", r.optR[3 * i], r.optR[3 * i + 1], r.optR[3 * i + 2], i == 2 ? "" : ",");
 	std::fprintf(f, "]\ntranslation = [%.9g, %.9g, %.9g]\n", r.optT[0], r.optT[1], r.optT[2]);
-	std::fprintf(f, "\n[stats]\nsource_points = %zu\ntarget_points = %zu\n", n_source, n_target);
+	std::fprintf(f, "\n[stats]\nsource_points = %zu\ninlier_points = %zu\ntarget_points = %zu\n", n_source, n_used, n_target);
 	std::fprintf(f, "rotation_nodes = %lld\ntranslation_nodes = %lld\ncube_bounds = %lld\ninner_bnb_calls = %lld\n",
 	             r.counters.rot_pops, r.counters.trans_pops, r.counters.cubes, r.counters.inner_calls);
 	std::fprintf(f, "icp_runs = %lld\nicp_iterations = %lld\nbounds_launches = %lld\n", r.counters.icp_runs,

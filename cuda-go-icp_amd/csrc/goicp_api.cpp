@@ -331,7 +331,7 @@ int goicp_poll(goicp_handle h, goicp_result* out)
 int goicp_result_write_toml(goicp_handle h, const char* path)
 {
 	REQUIRE(h && path);
-	return guarded([&] { goicp::write_result_toml(path, h->e->poll(), h->e->n_source(), h->e->n_target(), h->e->sse_threshold()); });
+	return guarded([&] { goicp::write_result_toml(path, h->e->poll(), h->e->n_source(), h->e->n_target(), h->e->sse_threshold(), h->e->inliers()); });
 }
 
 int goicp_result_write_ply(goicp_handle h, const char* path)

@@ -62,6 +62,20 @@ def spanner_to_f32(dst_target, dst_source):
     return out
 
 
+def bunny_icp_to_f32(dst_target, dst_source):
+    """test/bunny_icp.toml:10-20 (BASELINE configs[0]): target bun045.ply (40 097 points), source bun000.ply (40 256), resize 15,
+    subsample 1.0 -- through OUR loader, as the config says."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    pkg = load_pkg()
+    out = []
+    for name, dst in (("bun045.ply", dst_target), ("bun000.ply", dst_source)):
+        c = pkg.load_cloud(os.path.join(BUNNY, name), 1.0, 15.0)
+        np.ascontiguousarray(c, dtype="<f4").tofile(dst)
+        out.append(len(c))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -79,6 +93,7 @@ def main():
         print(name, n, "points")
     print("skull_scan", skull_to_f32(os.path.join(OUT, "skull_scan.f32")), "points")
     print("spanner target/source", spanner_to_f32(os.path.join(OUT, "spanner_target.f32"), os.path.join(OUT, "spanner_source.f32")), "points")
+    print("bunny_icp target/source", bunny_icp_to_f32(os.path.join(OUT, "bun045.f32"), os.path.join(OUT, "bun000.f32")), "points")
     if args.clouds_only:
         return
     procs = [
@@ -87,6 +102,9 @@ def main():
         subprocess.Popen([h, "e2e", OUT, "rand100", mr, dr, "1e-3", "1"], stdout=subprocess.DEVNULL),
         subprocess.Popen([h, "e2e", OUT, "bunny10", mb, db, "1e-3", "10"], stdout=subprocess.DEVNULL),
     ]
+    # exact cube-bound counts of bench.py's reference-baseline call sequence (DT3D::Distance calls / Nd)
+    subprocess.check_call([os.path.join(HERE, "_ref", "ref_harness_count"), "count", os.path.join(OUT, "model_bunny.f32"),
+                           os.path.join(OUT, "data_bunny.f32"), "240", os.path.join(OUT, "ref_bench_counts.json")])
     if not args.skip_full:
         procs.append(subprocess.Popen([h, "e2e", OUT, "bunny_full", mb, db, "1e-3", "1"], stdout=subprocess.DEVNULL))
     rc = [p.wait() for p in procs]

@@ -992,6 +992,16 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
             lib.goicp_thread_comm_destroy(comms[r])
         for e in engines:
             e.registration.close()
+    # trimmed engines: the global stop test uses the ENGINE's threshold (mse * inlierNum, jly_goicp.cpp:198-208)
+    one = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], trim_fraction=0.1)
+    assert abs(float(one.sse_threshold) - g["mse_threshold"] * int(len(bunny_data10) * np.float32(0.9))) < 1e-4
+    one.run()
+    pair = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], trim_fraction=0.1) for _ in range(2)]
+    sse, R, t, _ = sharded.run_local_ranks(pair, rot_pops_per_step=4)
+    assert sse < pair[0].sse_threshold and abs(sse - float(one.get_best_error())) <= float(one.sse_threshold)
+    assert rot_angle(R, one.optR) <= 5e-2
+    for e in [one] + pair:
+        e.registration.close()
 
 
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
@@ -1019,3 +1029,31 @@ def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     assert e.get_best_error() <= 1.02 * g["sse"] and e.get_best_error() < g["sse_threshold"]
     assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2
     e.registration.close()
+
+
+def test_bunny_icp_config0(pkg, oracle_mod):
+    """BASELINE configs[0], test/bunny_icp.toml:10-20 on the reference's own scans: target bun045.ply (40 097 points), source
+    bun000.ply (40 256), resize 15, plain ICP (modes 0-2 are the same arithmetic, src/icp_kernel.cu:48-279; the reference
+    iterates forever, its viewer shows the running pose).  The step API (ICP::kdTreeGPUStep -> goicp_icp_step) against the
+    oracle's ICP iteration with fresh means, step by step: 1e-4 abs on R, t over 15 steps; the error decreases monotonically."""
+    target, source = cloud("bun045"), cloud("bun000")
+    assert len(target) == 40097 and len(source) == 40256
+    reg = pkg.Registration(target, source, 1e-5)
+    kd = oracle_mod.KdTree(target)
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    errs = []
+    for _ in range(15):
+        snap = reg.icp_step()
+        e, R, t, _ = kd.icp_run(source, R, t, 1, -1e30)
+        errs.append(float(snap.best_sse))
+        assert abs(snap.best_sse - e) <= 1e-4 * e
+    assert np.abs(np.array(snap.curR, np.float32).reshape(3, 3) - R).max() <= 1e-4
+    assert np.abs(np.array(snap.curT, np.float32) - t).max() <= 1e-4
+    assert all(b <= a * (1 + 1e-5) for a, b in zip(errs, errs[1:]))
+    # exact NN on this target through the same hierarchy
+    rng = np.random.default_rng(3)
+    q = source[rng.choice(len(source), 1000, replace=False)]
+    idx, d2 = reg.nn_query(q)
+    bi, bd = oracle_mod.nn_brute(target, q)
+    assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
+    reg.close()

@@ -20,6 +20,16 @@ if which == "spanner":
         print("spanner mse %g: create %.2fs run %.3fs sse %.4f rot_err %.5f t_err %.5f rot_pops %d cubes %d icp %d launches %d" % (
             mse, t1 - t0, t2 - t1, eng.get_best_error(), rot_angle(eng.optR, Rgt), np.linalg.norm(eng.optT - tgt), c.rot_pops, c.cubes, c.icp_iters, c.bounds_launches), flush=True)
         eng.registration.close()
+elif which == "ksweep":
+    for K in (4, 8, 16, 32):
+        for rb in (64,):
+            best = None
+            for rep in range(3):
+                eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, trans_batch=K, rot_batch=rb)
+                t1 = time.time(); eng.run(); dt = time.time() - t1; c = eng.counters
+                best = min(best, dt) if best else dt
+                eng.registration.close()
+            print("K=%d rot_batch=%d: best %.4fs sse %.4f trans_pops %d cubes %d launches %d" % (K, rb, best, eng.get_best_error() if False else 0, c.trans_pops, c.cubes, c.bounds_launches), flush=True)
 elif which == "bunny":
     for dq in (1, 0, 1, 0):
         eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, verbose=1, device_queues=dq)

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		unsigned before = 0, total = 0;
 #pragma unroll
 		for (int w2 = 0; w2 < kQThreads / 64; w2++) { if (w2 < wave) before += sh.push_tot[w2]; total += sh.push_tot[w2]; }
-		if (count + (int)total > kQueueCap) {
+		if (count + (int)total > qp.cap) {
 			// does not fit: flag it; the host re-runs the whole batch through its own queues (nothing is lost)
 			if (tid == 0) { atomicExch(&ctl->overflow, 1); S->done = 1; S->n_parents = 0; }
 			return;

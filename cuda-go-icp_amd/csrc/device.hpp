@@ -104,6 +104,7 @@ struct QParams {
 	int32_t K;                      // expansions per search and round (<= kQueueMaxPop)
 	float root_x, root_y, root_z, root_w;
 	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
+	int32_t cap;                    // nodes a queue may hold (<= kQueueCap; smaller values only to exercise the overflow path)
 	float lo[3], hi[3];
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);

@@ -845,6 +845,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	qp.thr = sse_thresh_; qp.K = K;
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
+	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
 	for (int k = 0; k < 3; k++) { qp.lo[k] = trans_boxed_ ? trans_lo_[k] : 0.f; qp.hi[k] = trans_boxed_ ? trans_hi_[k] : 0.f; }
 	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
 	const int max_groups = (int)(S * (size_t)K);
@@ -866,7 +867,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		const double t1 = now_ms();
 		HIPCHK(hipStreamSynchronize(stream_));
 		t_wait_ += now_ms() - t1;
-		if (h_qctl_->overflow) { queue_fallbacks_++; return false; }
+		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
 		if (h_qctl_->n_groups[last] == 0 || cancel_.load()) break;
 		chunk = 4;
 	}
@@ -1002,7 +1003,7 @@ float Engine::inner_bnb(const float R[9], int level, float incumbent, float best
 	run_inner(v, rots);
 	if (best_node && s.improved) { best_node[0] = s.best_node.x; best_node[1] = s.best_node.y; best_node[2] = s.best_node.z; best_node[3] = s.best_node.w; }
 	cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
-	if (c) { c->trans_pops += s.pops; c->cubes += s.cubes; c->inner_calls++; }
+	if (c) { c->trans_pops += s.pops; c->cubes += s.cubes; c->inner_calls++; c->queue_fallbacks = cnt_.queue_fallbacks; }
 	return s.best;
 }
 

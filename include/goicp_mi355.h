@@ -118,6 +118,8 @@ typedef struct goicp_params {
 	                          * instead of two), rounded toward zero so that lower bounds stay valid; upper bounds come out low by
 	                          * <= 2^-10 relative.  ICP, the DT re-score of a pose and trimmed bounds keep the fp32 grid.  NOT the
 	                          * bit-parity path: opt-in, default 0 */
+	int32_t queue_cap;       /* test hook: nodes a device-resident queue may hold before its batch is re-run through the host queues
+	                          * (0 = the full 8 192-node slab) */
 	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner
 	                          * searches is two launches, no host round trip; 0: host-side queues (always used with trans_batch == 1,
 	                          * the reference visit order) */
@@ -184,6 +186,7 @@ int goicp_eval_sse(goicp_handle h, const float R[9], const float t[3], float* ss
  * (src/goicp/jly_goicp.cpp:227-340).  best_node = {corner x,y,z, width}, written only on improvement. */
 typedef struct goicp_counters {
 	int64_t rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters, bounds_launches;
+	int64_t queue_fallbacks;     /* batches of inner searches re-run through the host queues because a device queue outgrew its slab */
 } goicp_counters;
 int goicp_inner_bnb(goicp_handle h, const float R[9], int32_t level, float incumbent, float* value,
                     float best_node[4], goicp_counters* counters);

@@ -923,8 +923,20 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
     for e in (a, b):
         assert e.get_best_error() <= 1.02 * ge["sse"] and e.get_best_error() < ge["sse_threshold"]
         assert rot_angle(e.optR, np.array(ge["R"])) <= 3e-2
-    assert a.counters.bounds_launches > 0
-    for r in (dev, host, a.registration, b.registration):
+    assert a.counters.bounds_launches > 0 and a.counters.queue_fallbacks == 0
+    # the overflow path: with room for only 48 nodes per queue every long search outgrows its slab, the batch is flagged
+    # and re-run through the host queues -- same values as the host driver, and the fallback is counted
+    tiny = pkg.Registration(bunny_model, bunny_data10, 1e-3, device_queues=1, queue_cap=48)
+    case = g["cases"][0]
+    R0 = np.array(case["R"], np.float32)
+    full = case["full"][0]
+    vt, nt, ct = tiny.inner_bnb(R0, full["level"], full["incumbent"])
+    assert ct.queue_fallbacks >= 1 and abs(vt - full["value"]) <= thr
+    c = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, device_queues=1, queue_cap=48)
+    c.run()
+    assert c.counters.queue_fallbacks >= 1
+    assert c.get_best_error() <= 1.02 * ge["sse"] and c.get_best_error() < ge["sse_threshold"]
+    for r in (dev, host, tiny, a.registration, b.registration, c.registration):
         r.close()
 
 
@@ -1046,7 +1058,7 @@ def test_bunny_icp_config0(pkg, oracle_mod):
         snap = reg.icp_step()
         e, R, t, _ = kd.icp_run(source, R, t, 1, -1e30)
         errs.append(float(snap.best_sse))
-        assert abs(snap.best_sse - e) <= 1e-4 * e
+        assert abs(snap.best_sse - e) <= 2e-3 * e          # 40 256 float terms (sequential vs tree sum) on two trajectories that drift apart by ~1e-5 per step
     assert np.abs(np.array(snap.curR, np.float32).reshape(3, 3) - R).max() <= 1e-4
     assert np.abs(np.array(snap.curT, np.float32) - t).max() <= 1e-4
     assert all(b <= a * (1 + 1e-5) for a, b in zip(errs, errs[1:]))

@@ -8,7 +8,9 @@ Tolerances follow SURVEY.md 8(c).
 import numpy as np
 import pytest
 
-from conftest import cloud, golden, rot_angle
+import os
+
+from conftest import ROOT, cloud, golden, rot_angle
 
 
 def test_dt_geometry_exact(oracle_dt_bunny):
@@ -180,3 +182,15 @@ def test_inner_bnb_trimmed(oracle_mod, oracle_dt_bunny, bunny_data10):
             v, best, pops, _ = oracle_mod.inner_bnb_trim(oracle_dt_bunny, prot, r, k, s["incumbent"], g["sse_threshold"])
             assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
             assert abs(pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+
+
+@pytest.mark.slow
+def test_oracle_trim_fixture_is_current():
+    """tests/golden/e2e_bunny10_trim_oracle.json (what the GPU test of the trimmed registration compares with) is what
+    the oracle computes today (~50 s of CPU)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_oracle_fixtures as G
+    live, fix = G.trimmed_bunny10(), golden("e2e_bunny10_trim_oracle")
+    assert np.allclose(live["R"], fix["R"], atol=1e-6) and np.allclose(live["t"], fix["t"], atol=1e-6)
+    assert abs(live["sse"] - fix["sse"]) <= 1e-5 * fix["sse"]

@@ -359,7 +359,7 @@ def main():
         for name, mode, window in () if args.no_probe else (("coalesced_l1", 0, 16 << 10), ("coalesced_l2", 0, 2 << 20), ("coalesced_dt", 0, 1 << 40),
                                    ("divergent_l1", 1, 16 << 10), ("divergent_l2", 1, 2 << 20), ("divergent_dt", 1, 1 << 40),
                                    ("lines4_l2", 4, 2 << 20), ("lines8_l2", 8, 2 << 20), ("lines16_l2", 16, 2 << 20), ("lines32_l2", 32, 2 << 20),
-                                   ("lines16_l1", 16, 64 << 10), ("lines32_l1", 32, 64 << 10)):
+                                   ("lines16_l1", 16, 64 << 10), ("lines32_l1", 32, 64 << 10), ("lds_tile_gather", 2, 64 << 10)):
             v = C.c_double()
             B.check(lib.goicp_probe_gather(h, mode, window, C.byref(v)))
             probe[name] = round(v.value / 1e9, 2)

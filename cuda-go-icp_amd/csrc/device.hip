@@ -1508,8 +1508,37 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const float* __restri
 	if (acc == 1.2345e-30f) sink[0] = acc;      // never true for a distance field; keeps the loads alive
 }
 
+// MODE 2 of the probe: what an LDS-staged DT tile would deliver -- a 64 KiB tile of the grid copied into LDS once, then
+// the same independent 4-byte lookups at random tile addresses served by ds_read_b32 (bank conflicts included).
+__global__ __launch_bounds__(256) void probe_lds_kernel(const float* __restrict__ grid, unsigned n_floats, int iters, float* __restrict__ sink)
+{
+	__shared__ float tile[16384];
+	const unsigned base = (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % (n_floats - 16384u)) & ~63u;
+	for (int i = threadIdx.x; i < 16384; i += 256) tile[i] = grid[base + i];
+	__syncthreads();
+	unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;        // per-lane addresses: a gather
+	float acc = 0.f;
+	for (int it = 0; it < iters; it++) {
+		float v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			h = h * 1664525u + 1013904223u;
+			v[u] = tile[(h >> 9) & 16383u];
+		}
+#pragma unroll
+		for (int u = 0; u < 8; u++) acc += v[u];
+	}
+	if (acc == 1.2345e-30f) sink[0] = acc;
+}
+
 hipError_t launch_probe_gather(const DtDesc& dt, int mode, unsigned window, int blocks, int iters, float* sink, hipStream_t stream)
 {
+	if (mode == 2) {
+		const unsigned n = dt.layout ? (unsigned)dt.VB * dt.VB * dt.VB * 64u : (unsigned)dt.V * dt.V * dt.V;
+		if (n <= 16384u || dt.layout == 2) return hipErrorInvalidValue;
+		hipLaunchKernelGGL(probe_lds_kernel, dim3(blocks), dim3(256), 0, stream, dt.grid, n, iters, sink);
+		return hipGetLastError();
+	}
 	const unsigned n = dt.layout ? (unsigned)dt.VB * dt.VB * dt.VB * 64u : (unsigned)dt.V * dt.V * dt.V;
 	if (window < 4096u || (window & (window - 1u)) || window > n) return hipErrorInvalidValue;
 	switch (mode) {

@@ -735,7 +735,7 @@ double Engine::probe_gather(int mode, size_t window_bytes)
 	int cus = 256;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, dev_) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-	const int blocks = cus * 8, iters = 256;
+	const int blocks = mode == 2 ? cus * 2 : cus * 8, iters = 256;        // mode 2: 64 KiB of LDS per workgroup -> two per CU
 	float* sink = static_cast<float*>(scratch_bytes(64));
 	HIPCHK(launch_probe_gather(dt_, mode, window, blocks, iters, sink, stream_));   // warm-up
 	HIPCHK(hipStreamSynchronize(stream_));

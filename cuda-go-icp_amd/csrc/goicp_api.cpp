@@ -199,7 +199,7 @@ int goicp_set_progress_callback(goicp_handle h, goicp_progress_fn cb, void* user
 
 int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s)
 {
-	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1 || mode == 4 || mode == 8 || mode == 16 || mode == 32));
+	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 8 || mode == 16 || mode == 32));
 	return guarded([&] { *lookups_per_s = h->e->probe_gather(mode, window_bytes); });
 }
 

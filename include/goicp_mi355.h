@@ -313,7 +313,8 @@ int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz
  * goicp_probe_gather: measured ceiling of the path that bounds the cube-bound kernel -- independent 4-byte loads
  * into the engine's resident distance transform, nothing else.  mode 0: the 64 lanes of a wave-instruction read 64
  * consecutive floats; mode 1: 64 different 128-byte lines; mode k in {4, 8, 16, 32}: k distinct lines per instruction, the
- * lanes in k runs of 64/k consecutive floats (the cost curve between the two extremes).  window_bytes = footprint each workgroup draws its
+ * lanes in k runs of 64/k consecutive floats (the cost curve between the two extremes); mode 2: the lookups served from a
+ * 64 KiB tile staged in LDS (what an LDS-staged DT tile would deliver once it is loaded; window_bytes ignored).  window_bytes = footprint each workgroup draws its
  * addresses from (rounded up to a power of two, at least 16 KiB, at most the grid).  Result: lookups per second.
  * goicp_debug_kabsch: the device-side 3x3 SVD / Kabsch routine of the ICP update (Matrix::svd use in
  * src/goicp/jly_icp3d.hpp:266-285) on a caller-supplied H (row-major), on the current device; test-only. */

@@ -35,7 +35,7 @@ class CParams(C.Structure):
                 ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float),
                 ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
                 ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32),
-                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32)]
+                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32)]
 
 
 class CCube(C.Structure):
@@ -102,6 +102,7 @@ SYMBOLS = {
     "goicp_set_progress_callback": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     "goicp_probe_gather": (C.c_int, [_vp, C.c_int32, C.c_size_t, C.POINTER(C.c_double)]),
     "goicp_debug_kabsch": (C.c_int, [_fp, _fp]),
+    "goicp_debug_cache_hits": (C.c_int, [_vp, _fp, _fp, C.POINTER(C.c_int64)]),
     "goicp_create": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.POINTER(_vp)]),
     "goicp_destroy": (C.c_int, [_vp]),
     "goicp_dt_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -117,6 +118,7 @@ SYMBOLS = {
     "goicp_inner_bnb": (C.c_int, [_vp, _fp, C.c_int32, C.c_float, _fp, _fp, C.POINTER(CCounters)]),
     "goicp_icp_run": (C.c_int, [_vp, _fp, _fp, C.c_int32, C.c_float, _fp, C.POINTER(C.c_int32)]),
     "goicp_time_icp_pass": (C.c_int, [_vp, _fp, _fp, C.c_int32, _fp]),
+    "goicp_time_icp_pass_cached": (C.c_int, [_vp, _fp, _fp, C.c_int32, _fp]),
     "goicp_nn_query": (C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_int32), _fp]),
     "goicp_icp_step": (C.c_int, [_vp]),
     "goicp_register": (C.c_int, [_vp]),

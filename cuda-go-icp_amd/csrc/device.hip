@@ -773,12 +773,21 @@ __device__ __forceinline__ unsigned row_take(unsigned key[4], int l, int row, in
 // Exact 1-NN of the row's query.  `active` rows walk; the others idle through the loop.  On return
 // best/idx are uniform in the row and exactly one lane of an active row has `mine` set: the one whose
 // leaf slot holds the neighbour (its coordinates and slot ride along in that lane).
-struct RowNn { float best; int idx; bool mine; float mx, my, mz; int slot; };
+//
+// TWO: also return best2, a lower bound on the squared distance from the query to EVERY target point other than the
+// neighbour (the walk then prunes with the second-best distance; the DT seed takes part as a pseudo-candidate, which can
+// only make best2 smaller, i.e. more conservative).  The ICP pass caches (query position, neighbour, sqrt(best2)) per
+// source point: on a later pass at position q' the cached point m is still THE nearest neighbour whenever
+// |q' - m| + |q' - q_ref| < sqrt(best2_ref) -- every other point is at least sqrt(best2_ref) - |q' - q_ref| away -- so the
+// walk is skipped exactly, not approximately.
+struct RowNn { float best; int idx; bool mine; float mx, my, mz; int slot; float best2; };
 
-template <int K, int LAYOUT>
+template <int K, int LAYOUT, bool TWO = false>
 __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt, const Box6x4& rootb, int l, int row,
                                               float qx, float qy, float qz, bool active)
 {
+	// no row of this wavefront needs a walk (every query hit the neighbour cache): nothing to fetch, nothing to compute
+	if (!__any(active)) return RowNn{INFINITY, INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
 	unsigned key[K][4];
 	int node[K];                              // group index at each level; leaves of level K-1 are node*64 + c
 	node[0] = 0;
@@ -797,8 +806,9 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 		row_take(key[0], l, row, node[1]);
 		fb = load_child_boxes4(kd.boxes[1] + (size_t)node[1] * 384, l);
 	}
-	RowNn r{nn_upper_bound<LAYOUT>(dt, qx, qy, qz), INT_MAX, false, 0.f, 0.f, 0.f, 0};
+	RowNn r{nn_upper_bound<LAYOUT>(dt, qx, qy, qz), INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
 	unsigned bbits = __float_as_uint(r.best);
+	unsigned b2bits = 0x7f800000u;                // +inf: nothing but the neighbour seen yet
 	int d = 0;
 	if constexpr (K > 1) {
 		boxes_keys4(fb, qx, qy, qz, key[1]);
@@ -814,7 +824,7 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 			if (!acted && d == L) {
 				int c;
 				const unsigned m = row_take(key[L], l, row, c);
-				if ((m & ~3u) > bbits) {                             // nothing left within the best distance
+				if ((m & ~3u) > (TWO ? b2bits : bbits)) {            // nothing left within the best (TWO: second-best) distance
 					if (L == 0) { done = true; acted = true; }
 					else d = L - 1;
 				} else if (L == K - 1) {
@@ -822,7 +832,8 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 					int c2;
 					const unsigned m2 = row_take(key[L], l, row, c2);
 					const int sa = (node[L] * 64 + c) * kLeafSlots + l;
-					int sb = (node[L] * 64 + ((m2 & ~3u) > bbits ? c : c2)) * kLeafSlots + l;
+					const bool dup = (m2 & ~3u) > (TWO ? b2bits : bbits);   // no second leaf worth scanning: the first one twice
+					int sb = (node[L] * 64 + (dup ? c : c2)) * kLeafSlots + l;
 					const float4 pa = kd.pts[sa];
 					float4 pt = kd.pts[sb];
 					const float d0 = qx - pa.x, d1 = qy - pa.y, d2 = qz - pa.z;
@@ -833,11 +844,19 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 					float e = e0 * e0;
 					e += e1 * e1;
 					e += e2 * e2;
-					if (da < e || (da == e && __float_as_int(pa.w) < __float_as_int(pt.w))) { pt = pa; e = da; sb = sa; }
+					const bool a_wins = da < e || (da == e && __float_as_int(pa.w) < __float_as_int(pt.w));
+					const float other = dup ? INFINITY : (a_wins ? e : da);   // this lane's second candidate (TWO)
+					if (a_wins) { pt = pa; e = da; sb = sa; }
 					const unsigned db = __float_as_uint(e);
 					const unsigned dmin = row_min_u32(db);
 					const unsigned id = (unsigned)__float_as_int(pt.w);
 					const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);   // ties -> lowest original index
+					if constexpr (TWO) {
+						// the two smallest of {best, best2, this scan's candidates}: the scan's runner-up is the row minimum with
+						// the winning lane represented by its other candidate
+						const unsigned second = row_min_u32((db == dmin && id == idmin) ? __float_as_uint(other) : db);
+						b2bits = min(max(bbits, dmin), min(b2bits, second));
+					}
 					if (dmin < bbits || (dmin == bbits && (int)idmin < r.idx)) {
 						bbits = dmin;
 						r.idx = (int)idmin;
@@ -858,6 +877,7 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 		}
 	}
 	r.best = __uint_as_float(bbits);
+	r.best2 = __uint_as_float(b2bits);
 	return r;
 }
 
@@ -871,10 +891,14 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 // FUSED: the workgroup that arrives last (one ticket per launch; agent-scope release before the ticket, acquire
 // after it -- cdna_hip_programming.md Guideline 16, counter form) also runs the finalize, so an ICP iteration is ONE
 // launch.  `ticket` is zero between launches: zeroed when the engine is created, reset by the last arriver.
-template <int K, int LAYOUT, bool FUSED>
+// nn_cache (two float4 per source point: {q_ref.xyz, sqrt(best2_ref)}, {neighbour xyz, its original index}) != nullptr:
+// the exact skip test of rows_nearest<TWO>'s comment; entries never go stale (they are statements about the static
+// target cloud), an entry with sqrt(best2_ref) = 0 (fresh engine, tied neighbours) always walks.
+template <int K, int LAYOUT, bool FUSED, bool CACHE>
 __global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                   IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
-                                                                  float* __restrict__ partials, int* __restrict__ ticket)
+                                                                  float* __restrict__ partials, int* __restrict__ ticket,
+                                                                  float4* __restrict__ nn_cache, int* __restrict__ hit_counter)
 {
 	__shared__ FinScratch sh;
 	float (*red)[kIcpAcc] = sh.red;                                   // [16 rows of the workgroup][16 sums]
@@ -882,13 +906,38 @@ __global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* 
 	const int i = (blockIdx.x * (kIcpThreads / 64) + wave) * 4 + row;
 	const bool valid = i < N;
 	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
-	const float4 p = src[valid ? i : N - 1];
+	const int ic = valid ? i : N - 1;
+	const float4 p = src[ic];
+	float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+	if constexpr (CACHE) { c0 = nn_cache[2 * (size_t)ic]; c1 = nn_cache[2 * (size_t)ic + 1]; }   // same round trip as p
 	if (st->converged) return;                                   // loop already finished: queued launches drain
 	// jly_icp3d.hpp:222-224, left-to-right float sums
 	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
 	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
 	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-	const RowNn r = rows_nearest<K, LAYOUT>(kd, dt, rootb, l, row, qx, qy, qz, valid);
+	RowNn r;
+	if constexpr (CACHE) {
+		// exact skip test: the cached point is THE neighbour at q if |q - m| + |q - q_ref| < sqrt(best2_ref); a relative
+		// 1e-5 and an absolute 1e-7 cover the rounding of the three square roots and sums (a failed test only costs a walk)
+		const float e0 = qx - c1.x, e1 = qy - c1.y, e2 = qz - c1.z;
+		float e = e0 * e0;                                       // the leaf scan's accumulation order: the same bits
+		e += e1 * e1;
+		e += e2 * e2;
+		const float g0 = qx - c0.x, g1 = qy - c0.y, g2 = qz - c0.z;
+		const float moved = __fsqrt_rn(g0 * g0 + g1 * g1 + g2 * g2);
+		const bool hit = valid && (__fsqrt_rn(e) + moved) * 1.00001f + 1e-7f < c0.w;
+		r = rows_nearest<K, LAYOUT, true>(kd, dt, rootb, l, row, qx, qy, qz, valid && !hit);
+		if (hit_counter && hit && l == 0) atomicAdd(hit_counter, 1);      // diagnostics only (goicp_debug_cache_hits)
+		if (hit) {
+			r.best = e; r.idx = __float_as_int(c1.w); r.mine = l == 0; r.mx = c1.x; r.my = c1.y; r.mz = c1.z;
+		} else if (valid && r.mine) {
+			// the walk's result becomes the entry: position, neighbour, and what everything else is at least away
+			nn_cache[2 * (size_t)i] = make_float4(qx, qy, qz, __fsqrt_rn(r.best2) * 0.99999f);
+			nn_cache[2 * (size_t)i + 1] = make_float4(r.mx, r.my, r.mz, __int_as_float(r.idx));
+		}
+	} else {
+		r = rows_nearest<K, LAYOUT>(kd, dt, rootb, l, row, qx, qy, qz, valid);
+	}
 	float acc[kIcpAcc];
 #pragma unroll
 	for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.f;
@@ -1560,11 +1609,17 @@ int icp_blocks(int N)
 }
 
 template <int K, bool FUSED>
-static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, int* ticket, hipStream_t stream)
+static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, int* ticket, float4* nn_cache,
+                          int* hits, hipStream_t stream)
 {
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
-	if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket);
-	else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket);
+	if (nn_cache) {
+		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+	} else {
+		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, false>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, false>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+	}
 }
 
 template <int K>
@@ -1593,17 +1648,17 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 
 // ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                int* ticket, hipStream_t stream)
+                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream)
 {
 	if (ticket) {
-		if (kd.K == 1) launch_pass_k<1, true>(src, N, st, kd, dt, partials, ticket, stream);
-		else if (kd.K == 2) launch_pass_k<2, true>(src, N, st, kd, dt, partials, ticket, stream);
-		else launch_pass_k<3, true>(src, N, st, kd, dt, partials, ticket, stream);
+		if (kd.K == 1) launch_pass_k<1, true>(src, N, st, kd, dt, partials, ticket, nn_cache, hits, stream);
+		else if (kd.K == 2) launch_pass_k<2, true>(src, N, st, kd, dt, partials, ticket, nn_cache, hits, stream);
+		else launch_pass_k<3, true>(src, N, st, kd, dt, partials, ticket, nn_cache, hits, stream);
 		return hipGetLastError();
 	}
-	if (kd.K == 1) launch_pass_k<1, false>(src, N, st, kd, dt, partials, nullptr, stream);
-	else if (kd.K == 2) launch_pass_k<2, false>(src, N, st, kd, dt, partials, nullptr, stream);
-	else launch_pass_k<3, false>(src, N, st, kd, dt, partials, nullptr, stream);
+	if (kd.K == 1) launch_pass_k<1, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
+	else if (kd.K == 2) launch_pass_k<2, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
+	else launch_pass_k<3, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
 	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, partials, icp_blocks(N), st);
 	return hipGetLastError();
 }

@@ -136,8 +136,11 @@ struct IcpState {
 int icp_blocks(int N);           // workgroups per pass; partials must hold icp_blocks(N)*kIcpAcc floats
 // ticket: a device int that is zero between launches -> ONE fused launch (the last workgroup to arrive runs the
 // finalize); nullptr -> two launches (pass, finalize).  Same arithmetic and summation order: bit-identical states.
+// nn_cache: 2 float4 per source point, zero-initialised once (never invalidated: its entries are statements about the
+// static target cloud) -> a pass skips, exactly, the tree walk of every query whose cached neighbour is provably still the
+// nearest; nullptr -> every query walks.
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, int* ticket, hipStream_t stream);
+                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,

@@ -400,6 +400,10 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		HIPCHK(hipMalloc(&d_include_, N_));
 	}
 	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
+	if (p_.icp_nn_cache) {
+		HIPCHK(hipMalloc(&d_nn_cache_, sizeof(float4) * 2 * N_));
+		HIPCHK(hipMemsetAsync(d_nn_cache_, 0, sizeof(float4) * 2 * N_, stream_));      // sqrt(best2_ref) = 0: the first pass walks
+	}
 	HIPCHK(hipMalloc(&d_icp_ticket_, 64));
 	HIPCHK(hipMemset(d_icp_ticket_, 0, 64));
 	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState)));
@@ -450,7 +454,7 @@ void Engine::release()
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
-	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_); hipFree(d_icp_ticket_); d_icp_ticket_ = nullptr;
+	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_); hipFree(d_icp_ticket_); d_icp_ticket_ = nullptr; hipFree(d_nn_cache_); d_nn_cache_ = nullptr;
 	hipFree(d_nn_d2_); hipFree(d_nn_slot_); hipFree(d_include_);
 	for (Stage& st : stage_) {
 		hipFree(st.d_parents); hipFree(st.d_ub);
@@ -677,7 +681,8 @@ void Engine::icp_launch_one()
 	if (inliers_ < (int)N_)
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
-		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr, stream_));
+		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
+		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_));
 }
 
 void Engine::icp_state_fetch()
@@ -709,10 +714,16 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 	return st.err_new;
 }
 
-float Engine::time_icp_pass(const float R[9], const float t[3], int iters)
+float Engine::time_icp_pass(const float R[9], const float t[3], int iters, bool cached)
 {
 	DeviceGuard guard(dev_);
-	icp_state_init(R, t, 0.f, 0, 1);   // frozen: every pass does the same work
+	// frozen state: every pass does the same work.  cached = false: the neighbour cache is bypassed, every query walks the
+	// tree (the cost of a pass at a new pose); cached = true: the pose repeats, so after the first pass every query hits
+	const int keep = p_.icp_nn_cache;
+	struct Restore { int& r; int v; ~Restore() { r = v; } } restore{p_.icp_nn_cache, keep};
+	if (!cached) p_.icp_nn_cache = 0;
+	else if (!d_nn_cache_) throw std::invalid_argument("goicp: the neighbour cache is disabled for this engine");
+	icp_state_init(R, t, 0.f, 0, 1);
 	icp_launch_one();
 	HIPCHK(hipStreamSynchronize(stream_));
 	HIPCHK(hipEventRecord(ev0_, stream_));
@@ -757,6 +768,23 @@ void debug_kabsch(const float H[9], float R[9])
 	HIPCHK(launch_kabsch_debug(buf.p, buf.p + 9, nullptr));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(R, buf.p + 9, sizeof(float) * 9, hipMemcpyDeviceToHost));
+}
+
+long long Engine::debug_cache_hits(const float R[9], const float t[3])
+{
+	// two scoring passes at the same pose: the second one's queries should all hit the neighbour cache
+	DeviceGuard guard(dev_);
+	if (!d_nn_cache_ || !p_.icp_nn_cache) return -1;
+	icp_state_init(R, t, 0.f, 0, 1);
+	icp_launch_one();
+	HIPCHK(hipMemsetAsync(d_icp_ticket_ + 8, 0, sizeof(int), stream_));
+	count_hits_ = true;
+	struct Off { bool& b; ~Off() { b = false; } } off{count_hits_};
+	icp_launch_one();
+	int hits = 0;
+	HIPCHK(hipMemcpyAsync(&hits, d_icp_ticket_ + 8, sizeof(int), hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	return hits;
 }
 
 void Engine::icp_step()

@@ -30,6 +30,7 @@ struct Params {
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
 	int bounds_fp16 = 0;          // 1: BnB cube bounds read a half-precision copy of the bricked DT (rounded toward zero: lower bounds stay valid, upper bounds low by <= 2^-10 relative); ICP, the DT re-score and trimmed bounds keep the fp32 grid.  Not bit-parity: opt-in
+	int icp_nn_cache = 0;         // 1: an ICP pass skips (exactly) the tree walk of every query whose cached neighbour is provably still the nearest (measured slower on real trajectories, DESIGN 3.6: opt-in); 0: every query walks every pass; bit-identical states either way
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
@@ -93,11 +94,12 @@ public:
 	float eval_sse(const float R[9], const float t[3]);
 	float inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c);
 	float icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters);
-	float time_icp_pass(const float R[9], const float t[3], int iters);
+	float time_icp_pass(const float R[9], const float t[3], int iters, bool cached = false);   // cached: every query hits the neighbour cache (steady state); else every query walks
 	void nn_query(const float* q_xyz, size_t n, int32_t* idx, float* d2);
 	void icp_step();   // one ICP iteration on the engine's current pose (ICP::kdTreeGPUStep)
 	// measured ceiling of the gather path (4-byte loads into the resident DT): lookups/s; mode 0 coalesced, 1 divergent
 	double probe_gather(int mode, size_t window_bytes);
+	long long debug_cache_hits(const float R[9], const float t[3]);   // queries of a repeated pass that skipped the tree walk (-1: cache off)
 
 	// ---- registration ----
 	void run();                                  // FastGoICP::run / GoICP::Register
@@ -210,6 +212,8 @@ private:
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
+	float4* d_nn_cache_ = nullptr;     // per source point: {q_ref, sqrt(best2_ref)}, {neighbour, index} (exact walk-skipping, device.hip)
+	bool count_hits_ = false;
 	int* d_icp_ticket_ = nullptr;      // arrival ticket of the fused ICP iteration (zero between launches)
 	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only
 	void icp_launch_one();

@@ -112,7 +112,7 @@ void goicp_params_default(goicp_params* p)
 		p->trans_min[k] = d.trans_min[k]; p->trans_max[k] = d.trans_max[k];
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
-	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
+	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->icp_nn_cache = d.icp_nn_cache; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -155,7 +155,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 				p.trans_min[k] = params->trans_min[k]; p.trans_max[k] = params->trans_max[k];
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
-			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
+			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.icp_nn_cache = params->icp_nn_cache; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }
@@ -201,6 +201,12 @@ int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double
 {
 	REQUIRE(h && lookups_per_s && (mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 8 || mode == 16 || mode == 32));
 	return guarded([&] { *lookups_per_s = h->e->probe_gather(mode, window_bytes); });
+}
+
+int goicp_debug_cache_hits(goicp_handle h, const float R[9], const float t[3], int64_t* hits)
+{
+	REQUIRE(h && R && t && hits);
+	return guarded([&] { *hits = h->e->debug_cache_hits(R, t); });
 }
 
 int goicp_debug_kabsch(const float H[9], float R[9])
@@ -293,6 +299,12 @@ int goicp_time_icp_pass(goicp_handle h, const float R[9], const float t[3], int3
 {
 	REQUIRE(h && R && t && iters > 0 && ms);
 	return guarded([&] { *ms = h->e->time_icp_pass(R, t, iters); });
+}
+
+int goicp_time_icp_pass_cached(goicp_handle h, const float R[9], const float t[3], int32_t iters, float* ms)
+{
+	REQUIRE(h && R && t && iters > 0 && ms);
+	return guarded([&] { *ms = h->e->time_icp_pass(R, t, iters, true); });
 }
 
 int goicp_nn_query(goicp_handle h, const float* q, size_t n, int32_t* index, float* dist_sq)

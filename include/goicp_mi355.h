@@ -118,6 +118,10 @@ typedef struct goicp_params {
 	                          * instead of two), rounded toward zero so that lower bounds stay valid; upper bounds come out low by
 	                          * <= 2^-10 relative.  ICP, the DT re-score of a pose and trimmed bounds keep the fp32 grid.  NOT the
 	                          * bit-parity path: opt-in, default 0 */
+	int32_t icp_nn_cache;    /* opt-in (default 0; measured slower on real ICP trajectories).  1: the ICP pass keeps, per source point, its last neighbour m, the position q_ref it was found at
+	                          * and a lower bound s on the distance from q_ref to every OTHER target point (a 2-nearest walk); at a later
+	                          * position q the walk is skipped whenever |q - m| + |q - q_ref| < s, which proves m is still THE nearest
+	                          * neighbour -- exact, not approximate; 0: every query walks the tree in every pass (bit-identical results) */
 	int32_t queue_cap;       /* test hook: nodes a device-resident queue may hold before its batch is re-run through the host queues
 	                          * (0 = the full 8 192-node slab) */
 	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner
@@ -197,6 +201,9 @@ int goicp_icp_run(goicp_handle h, float R[9], float t[3], int32_t max_iter, floa
                   float* err, int32_t* iters);
 /* average duration (ms) of one ICP correspondence pass (NN + sums) at the given pose */
 int goicp_time_icp_pass(goicp_handle h, const float R[9], const float t[3], int32_t iters, float* ms_per_pass);
+/* the same with the neighbour cache in play at a repeated pose: every query hits (the steady-state floor of a pass);
+ * goicp_time_icp_pass itself bypasses the cache: every query walks the tree (a pass at a new pose) */
+int goicp_time_icp_pass_cached(goicp_handle h, const float R[9], const float t[3], int32_t iters, float* ms_per_pass);
 
 /* kernKDSearchNearest (src/icp_kernel.cu:146-157) / kernFindNearestNeighbor (src/fgoicp/icp3d.cu:13-30):
  * exact 1-NN of n query points in the target; ties -> lowest target index. */
@@ -320,6 +327,9 @@ int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz
  * src/goicp/jly_icp3d.hpp:266-285) on a caller-supplied H (row-major), on the current device; test-only. */
 int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s);
 int goicp_debug_kabsch(const float H[9], float R[9]);
+/* diagnostics of the ICP pass's neighbour cache: two scoring passes at (R, t); *hits = queries of the second pass that
+ * skipped the tree walk (-1 when the cache is off) */
+int goicp_debug_cache_hits(goicp_handle h, const float R[9], const float t[3], int64_t* hits);
 
 #ifdef __cplusplus
 }

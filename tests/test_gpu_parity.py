@@ -1072,3 +1072,34 @@ def test_bunny_icp_config0(pkg, oracle_mod):
     bi, bd = oracle_mod.nn_brute(target, q)
     assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
     reg.close()
+
+
+def test_icp_neighbour_cache_is_exact(pkg, oracle_mod, bunny_model, bunny_data):
+    """The ICP pass skips the tree walk of a query when its cached neighbour is PROVABLY still the nearest
+    (|q - m| + |q - q_ref| < the 2-nearest bound found at q_ref): not an approximation, so an ICP run with the cache is
+    bit-identical to one without it -- pose, error and iteration count -- from two start poses, full cloud; and the
+    correspondences behind a pass at the converged pose are the brute-force nearest neighbours."""
+    a = pkg.Registration(bunny_model, bunny_data, 1e-3, icp_nn_cache=1)
+    b = pkg.Registration(bunny_model, bunny_data, 1e-3, icp_nn_cache=0)
+    for R0, t0 in ((np.eye(3), np.zeros(3)), (pkg.fgoicp.rodrigues([0.2, -0.1, 0.15]), np.array([0.05, 0.02, -0.03]))):
+        for iters in (1, 7, 60, 10000):
+            ea, Ra, ta = pkg.IterativeClosestPoint3D(a, iters, 1e-7, R0, t0).run()
+            eb, Rb, tb = pkg.IterativeClosestPoint3D(b, iters, 1e-7, R0, t0).run()
+            assert ea == eb and np.array_equal(Ra, Rb) and np.array_equal(ta, tb), (iters, ea, eb)
+    # the error of a pass = sum of exact NN distances at that pose (cache warm from the runs above)
+    icp = pkg.IterativeClosestPoint3D(a, 10000, 1e-7, np.eye(3), np.zeros(3))
+    e, R, t = icp.run()
+    moved = (bunny_data @ R.T + t).astype(np.float32)
+    e1, _, _ = pkg.IterativeClosestPoint3D(a, 1, 1e-7, R, t).run()
+    q = np.ascontiguousarray(a.transform_source(R, t))
+    _, bd = oracle_mod.nn_brute(bunny_model, q[::7])
+    idx, d2 = a.nn_query(q[::7])
+    assert np.array_equal(d2, bd)
+    assert abs(e1 - d2.astype(np.float64).sum() * 7) <= 0.05 * e1          # sanity: same scale (every 7th point)
+    import ctypes as C
+    hits = C.c_int64()
+    fpc = lambda x: np.ascontiguousarray(x, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    Rf, tf = np.ascontiguousarray(R, np.float32).reshape(9), np.ascontiguousarray(t, np.float32)
+    pkg.binding.check(pkg.load_library().goicp_debug_cache_hits(a.handle, Rf.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_float)), C.byref(hits)))
+    assert hits.value >= 0.99 * len(bunny_data)                             # a repeated pose: (almost) every query skips its walk
+    a.close(); b.close()

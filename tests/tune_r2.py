@@ -30,6 +30,17 @@ elif which == "ksweep":
                 best = min(best, dt) if best else dt
                 eng.registration.close()
             print("K=%d rot_batch=%d: best %.4fs sse %.4f trans_pops %d cubes %d launches %d" % (K, rb, best, eng.get_best_error() if False else 0, c.trans_pops, c.cubes, c.bounds_launches), flush=True)
+elif which == "ramp":
+    for ramp in (4, 8, 16, 32, 64):
+        for rb in (32, 64, 128, 256):
+            os.environ["GOICP_RAMP"] = str(ramp)
+            best = None
+            for rep in range(3):
+                eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, rot_batch=rb)
+                t1 = time.time(); eng.run(); dt = time.time() - t1; c = eng.counters
+                best = min(best, dt) if best else dt
+                eng.registration.close()
+            print("ramp=%d rot_batch=%d: best %.4fs rot_pops %d cubes %d launches %d icp %d" % (ramp, rb, best, c.rot_pops, c.cubes, c.bounds_launches, c.icp_iters), flush=True)
 elif which == "bunny":
     for dq in (1, 0, 1, 0):
         eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, verbose=1, device_queues=dq)

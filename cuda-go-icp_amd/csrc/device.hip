@@ -1493,6 +1493,20 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 	if (lane == 0) { state->err = err_new; state->err_new = err_new; state->passes = passes; state->iters = iters; }
 }
 
+// Large clouds (1 M queries = 62 500 partial rows): a single workgroup reading them all is an 85 us tail on a 1.1 ms pass.
+// One more level: workgroup b sums the rows [b * rows_per_block, ...) in double, fixed order, and writes ONE float row; the
+// finalize then reads nblocks / rows_per_block rows.
+constexpr int kPreThreads = 256, kPreRows = 1024;
+__global__ __launch_bounds__(kPreThreads) void icp_partials_reduce(const float* __restrict__ partials, int nblocks, const IcpState* __restrict__ state,
+                                                                   float* __restrict__ out)
+{
+	__shared__ FinScratch sh;
+	if (state->converged) return;
+	const int b0 = blockIdx.x * kPreRows;
+	finalize_reduce<kPreThreads>(partials + (size_t)b0 * kIcpAcc, min(kPreRows, nblocks - b0), sh);
+	if (threadIdx.x < kIcpAcc) out[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = (float)sh.sums[threadIdx.x];
+}
+
 __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* __restrict__ partials, int nblocks,
                                                                    IcpState* __restrict__ state)
 {
@@ -1602,6 +1616,12 @@ hipError_t launch_probe_gather(const DtDesc& dt, int mode, unsigned window, int 
 	return hipGetLastError();
 }
 
+size_t icp_partials_floats(int N)     // the pass's rows + the rows of the intermediate level (large clouds)
+{
+	const size_t nb = (size_t)icp_blocks(N);
+	return (nb + (nb + kPreRows - 1) / kPreRows) * kIcpAcc;
+}
+
 int icp_blocks(int N)
 {
 	const int per_block = (kIcpThreads / 64) * 4;      // four queries per wavefront
@@ -1659,7 +1679,16 @@ hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const Kd
 	if (kd.K == 1) launch_pass_k<1, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
 	else if (kd.K == 2) launch_pass_k<2, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
 	else launch_pass_k<3, false>(src, N, st, kd, dt, partials, nullptr, nn_cache, hits, stream);
-	hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, partials, icp_blocks(N), st);
+	const int nb = icp_blocks(N);
+	if (nb > 4 * kPreRows) {
+		// two-level sum: the reduced rows live behind the pass's own rows in the same buffer (icp_partials_floats sizes it)
+		float* reduced = partials + (size_t)nb * kIcpAcc;
+		const int nb2 = (nb + kPreRows - 1) / kPreRows;
+		hipLaunchKernelGGL(icp_partials_reduce, dim3(nb2), dim3(kPreThreads), 0, stream, partials, nb, st, reduced);
+		hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, reduced, nb2, st);
+	} else {
+		hipLaunchKernelGGL(icp_finalize_update, dim3(1), dim3(kFinThreads), 0, stream, partials, nb, st);
+	}
 	return hipGetLastError();
 }
 

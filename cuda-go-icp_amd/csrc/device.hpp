@@ -133,7 +133,8 @@ struct IcpState {
 	int32_t carry_means;         // 1: the reference's carried means; 0: fresh means (single-step API)
 	int32_t frozen;              // 1: passes only score, the pose is not updated
 };
-int icp_blocks(int N);           // workgroups per pass; partials must hold icp_blocks(N)*kIcpAcc floats
+int icp_blocks(int N);           // workgroups per pass
+size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_icp_iteration must hold
 // ticket: a device int that is zero between launches -> ONE fused launch (the last workgroup to arrive runs the
 // finalize); nullptr -> two launches (pass, finalize).  Same arithmetic and summation order: bit-identical states.
 // nn_cache: 2 float4 per source point, zero-initialised once (never invalidated: its entries are statements about the

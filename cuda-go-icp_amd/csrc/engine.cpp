@@ -393,7 +393,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		kd_.pts = d_kd_pts_; kd_.M = (int)M_;
 	}
 	lap("k-d hierarchy + upload");
-	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * (size_t)std::max(icp_blocks((int)N_), icp_trim_blocks((int)N_)) * kIcpAcc));
+	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * std::max(icp_partials_floats((int)N_), (size_t)icp_trim_blocks((int)N_) * kIcpAcc)));
 	if (inliers_ < (int)N_) {
 		HIPCHK(hipMalloc(&d_nn_d2_, sizeof(float) * N_));
 		HIPCHK(hipMalloc(&d_nn_slot_, sizeof(int) * N_));

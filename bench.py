@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--bounds-fp16", type=int, default=0, help="opt-in half-precision DT copy for the BnB bounds (not the bit-parity path)")
     ap.add_argument("--icp-fused", type=int, default=-1, help="tuning only: ICP iteration as one fused launch 1 / pass + finalize 0 / engine default -1")
     ap.add_argument("--icp-nn-cache", type=int, default=0, help="tuning only: exact walk-skipping neighbour cache of the ICP pass 1 / off 0")
+    ap.add_argument("--flow", type=int, default=0, help="tuning only: continuous flow of the outer search (low-water mark of running inner searches) / lock-step batches 0")
     ap.add_argument("--device-queues", type=int, default=1, help="tuning only: inner-BnB queues on the device 1 / host 0")
     ap.add_argument("--no-probe", action="store_true", help="profiling runs: skip the gather-ceiling probes and the generic-path leg")
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
@@ -455,7 +456,7 @@ def main():
         e2e = None
         if not args.no_e2e:
             eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, kd_gpu_build=args.kd_gpu_build,
-                                bounds_fp16=args.bounds_fp16, device_queues=args.device_queues, icp_nn_cache=args.icp_nn_cache,
+                                bounds_fp16=args.bounds_fp16, device_queues=args.device_queues, icp_nn_cache=args.icp_nn_cache, flow=args.flow,
                                 **({"icp_fused": args.icp_fused} if args.icp_fused >= 0 else {}))
             t1 = time.perf_counter()
             eng.run()

@@ -35,7 +35,7 @@ class CParams(C.Structure):
                 ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float),
                 ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
                 ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32),
-                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32)]
+                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("flow", C.c_int32), ("adaptive_k", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32)]
 
 
 class CCube(C.Structure):

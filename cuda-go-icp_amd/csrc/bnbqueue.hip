@@ -28,10 +28,11 @@ namespace goicp {
 
 namespace {
 
-constexpr int kQThreads = 256;
-constexpr int kQPer = kQueueCap / kQThreads;      // keys per thread held in registers (32)
-static_assert(kQueueCap % kQThreads == 0 && kQPer == 32, "queue capacity is sized for 32 keys per thread");
-static_assert(kQueueMaxPop <= 32, "the selection bookkeeping handles at most 32 expansions per search and round");
+// 1 024 threads per search: one thread per child in the digest (8 x 128 expansions), 8 queue keys per thread in the selection
+constexpr int kQThreads = 1024;
+constexpr int kQPer = kQueueCap / kQThreads;      // keys per thread held in registers (8)
+static_assert(kQueueCap % kQThreads == 0 && kQPer <= 64, "queue capacity / threads = keys per thread");
+static_assert(8 * kQueueMaxPop <= kQThreads && kQueueMaxPop <= 128, "one thread per child; the hole filling uses two wavefronts");
 
 struct QShared {
 	unsigned hist[2048];
@@ -44,6 +45,7 @@ struct QShared {
 	int red_idx[kQThreads / 64];
 	unsigned push_tot[kQThreads / 64];
 	int n_sel, n_holes, parent_off, bcast;
+	int hole_cnt[2], fill_cnt[2];
 };
 
 __device__ __forceinline__ int node_depth(float root_w, float w)      // w = root_w * 2^-depth exactly
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 				if (live) atomicAdd(&sh.hist[(key[j] >> shift) & (unsigned)(bins - 1)], 1u);
 			}
 			__syncthreads();
-			// the bin holding the rem-th smallest candidate: eight bins per thread, wavefront scan, wavefront totals
-			unsigned h[8], local = 0;
+			// the bin holding the rem-th smallest candidate: 2048 / threads bins per thread, wavefront scan, wavefront totals
+			constexpr int kBins = 2048 / kQThreads;
+			unsigned h[kBins], local = 0;
 #pragma unroll
-			for (int b = 0; b < 8; b++) { h[b] = sh.hist[8 * tid + b]; local += h[b]; }
+			for (int b = 0; b < kBins; b++) { h[b] = sh.hist[kBins * tid + b]; local += h[b]; }
 			unsigned incl = local;
 #pragma unroll
 			for (int o = 1; o < 64; o <<= 1) {
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			if (excl < want && want <= excl + local) {                        // exactly one thread
 				unsigned cum = excl;
 #pragma unroll
-				for (int b = 0; b < 8; b++) {
+				for (int b = 0; b < kBins; b++) {
 					if (cum < want && want <= cum + h[b]) {
-						sh.sel_prefix = (prefix << width) | (unsigned)(8 * tid + b);
+						sh.sel_prefix = (prefix << width) | (unsigned)(kBins * tid + b);
 						sh.sel_rem = want - cum;
 					}
 					cum += h[b];
@@ -315,21 +318,24 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	}
 	__syncthreads();
 	// remove the selected nodes: the holes among the first m = n - n_sel positions are filled, in order, with the
-	// unselected nodes of the tail [m, n)  (at most n_sel of each; one wavefront does it)
+	// unselected nodes of the tail [m, n)  (at most n_sel <= 128 of each: the first two wavefronts do it)
 	const int m = n - n_sel;
-	if (wave == 0) {
-		const bool is_hole = lane < n_sel && sh.sel_pos[lane] < m;
-		const unsigned long long hb = __ballot(is_hole);
-		if (is_hole) sh.hole_pos[__popcll(hb & ((1ull << lane) - 1ull))] = sh.sel_pos[lane];
-		const int tailpos = m + lane;
-		bool filler = lane < n_sel && tailpos < n;
+	{
+		const bool is_hole = tid < n_sel && sh.sel_pos[tid < kQueueMaxPop ? tid : 0] < m;
+		const int tailpos = m + tid;
+		bool filler = tid < n_sel && tailpos < n;
 		if (filler)
 			for (int r = 0; r < n_sel; r++) if (sh.sel_pos[r] == tailpos) filler = false;
-		const unsigned long long fb = __ballot(filler);
+		const unsigned long long hb = __ballot(is_hole), fb = __ballot(filler);
+		if (wave < 2 && lane == 0) { sh.hole_cnt[wave] = (int)__popcll(hb); sh.fill_cnt[wave] = (int)__popcll(fb); }
+		__syncthreads();
+		const int hrank = (wave == 1 ? sh.hole_cnt[0] : 0) + (int)__popcll(hb & ((1ull << lane) - 1ull));
+		const int frank = (wave == 1 ? sh.fill_cnt[0] : 0) + (int)__popcll(fb & ((1ull << lane) - 1ull));
+		if (is_hole) sh.hole_pos[hrank] = sh.sel_pos[tid];
 		QNode moved{};
 		if (filler) moved = Q[tailpos];
-		__builtin_amdgcn_wave_barrier();
-		if (filler) Q[sh.hole_pos[__popcll(fb & ((1ull << lane) - 1ull))]] = moved;
+		__syncthreads();
+		if (filler) Q[sh.hole_pos[frank]] = moved;
 	}
 	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; }
 }
@@ -346,6 +352,26 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
 	S.bx = S.by = S.bz = S.bw = 0.f;
+}
+
+// the listed slots become fresh searches (continuous flow: slots are recycled while other searches keep running)
+__global__ void bnb_init_list_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, const QInit* __restrict__ list, int n, QParams qp)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const QInit in = list[i];
+	q[(size_t)in.slot * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};
+	QSearch& S = searches[in.slot];
+	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot;
+	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
+	S.bx = S.by = S.bz = S.bw = 0.f;
+}
+
+hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(bnb_init_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, searches, q, d_list, n, qp);
+	return hipGetLastError();
 }
 
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream)

@@ -82,7 +82,7 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 
 // ---- device-resident inner BnB (bnbqueue.hip): one queue per inner search, rounds without the host --------------
 constexpr int kQueueCap = 8192;     // nodes per search queue (a queue that would overflow sends the batch back to the host driver)
-constexpr int kQueueMaxPop = 32;    // most expansions per search and round
+constexpr int kQueueMaxPop = 128;   // most expansions per search and round (the driver uses 32 while many searches run and raises it for the stragglers)
 struct QNode { float x, y, z, w, ub, lb; };                    // corner + width (TRANSNODE, jly_goicp.h:59-72)
 struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:227-340)
 	float best;                     // optErrorT (in: the incumbent; out: the search's value)
@@ -108,6 +108,8 @@ struct QParams {
 	float lo[3], hi[3];
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
+struct QInit { int32_t slot; float best; float coeff; int32_t rot; };
+hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream);
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
                             const float* ubs, const float* lbs, QCtl* ctl, int parity, hipStream_t stream);

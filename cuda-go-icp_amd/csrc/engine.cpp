@@ -411,7 +411,13 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	if (p_.device_queues && p_.trans_batch > 1 && p_.wide_children) {
 		// the device-resident inner-BnB queues, sized for a full round of the outer search, and their pinned mirror touched
 		// once (the first use of a fresh pinned block costs milliseconds -- measured 8 ms inside the first registration)
-		ensure_queues(1);
+		ensure_queues(flow_mode() ? kFlowSearches : 1);
+		if (flow_mode()) {
+			ensure_batch(1, kFlowSearches / 2);
+			HIPCHK(hipHostMalloc(&h_qinit_, sizeof(QInit) * kFlowSearches));
+			HIPCHK(hipMalloc(&d_qinit_, sizeof(QInit) * kFlowSearches));
+			std::memset(h_qinit_, 0, sizeof(QInit) * kFlowSearches);
+		}
 		std::memset(h_qsearch_, 0, sizeof(QSearch) * cap_qsearch_);
 		HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyHostToDevice, stream_));
 		HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyDeviceToHost, stream_));
@@ -426,6 +432,28 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 		std::memcpy(rot[0].r, I9, sizeof(I9));
 		run_inner_device(one, rot);
+		if (flow_mode()) {
+			// the same for the continuous-flow driver: its list-init kernel, the full-size rotation table upload and the
+			// full-size read-back of the search records, once, here
+			const QParams qp = queue_params();
+			flow_reset();
+			h_qinit_[0] = QInit{0, 0.f, 0.f, 0};
+			std::memcpy(h_rots_[0].r, I9, sizeof(I9));
+			HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * (kFlowSearches / 2), hipMemcpyHostToDevice, stream_));
+			HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * kFlowSearches, hipMemcpyHostToDevice, stream_));
+			HIPCHK(launch_bnb_init_list(d_qsearch_, d_qnodes_, d_qinit_, 1, qp, stream_));
+			for (int r = 0; r < 3; r++) {
+				HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, kFlowSearches, qp, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qctl_, q_parity_, stream_));
+				HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0],
+				                           kFlowSearches * qp.K, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+				q_parity_ ^= 1;
+			}
+			HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+			HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * kFlowSearches, hipMemcpyDeviceToHost, stream_));
+			HIPCHK(hipStreamSynchronize(stream_));
+			flow_reset();
+			HIPCHK(hipStreamSynchronize(stream_));
+		}
 		cnt_ = Counters{};
 		queue_rounds_ = 0;
 	}
@@ -447,6 +475,7 @@ void Engine::release()
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
 	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
+	hipFree(d_qinit_); hipHostFree(h_qinit_); d_qinit_ = nullptr; h_qinit_ = nullptr;
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_); hipFree(d_dt16_); d_dt16_ = nullptr;
@@ -869,18 +898,14 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		q.best = searches[i]->best; q.coeff = searches[i]->coeff; q.rot = searches[i]->rot_slot;
 	}
 	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * S, hipMemcpyHostToDevice, stream_));
-	QParams qp{};
-	qp.thr = sse_thresh_; qp.K = K;
-	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
-	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
-	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
-	for (int k = 0; k < 3; k++) { qp.lo[k] = trans_boxed_ ? trans_lo_[k] : 0.f; qp.hi[k] = trans_boxed_ ? trans_hi_[k] : 0.f; }
+	QParams qp = queue_params();
+	qp.K = K;
 	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
-	const int max_groups = (int)(S * (size_t)K);
 	int parity = 0, chunk = 3;
 	while (true) {
 		const double t0 = now_ms();
 		int last = 0;
+		const int max_groups = (int)(S * (size_t)qp.K);
 		for (int r = 0; r < chunk; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qctl_, parity, stream_));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], max_groups,
@@ -898,6 +923,13 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
 		if (h_qctl_->n_groups[last] == 0 || cancel_.load()) break;
 		chunk = 4;
+		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
+		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
+		// costs nothing the chip was using)
+		if (p_.adaptive_k && K >= 32) {
+			const int active_est = (h_qctl_->n_groups[last] + qp.K - 1) / qp.K;       // searches that filled their quota
+			qp.K = active_est <= 16 ? kQueueMaxPop : (active_est <= 64 ? std::min(kQueueMaxPop, 2 * K) : K);
+		}
 	}
 	const double t2 = now_ms();
 	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
@@ -1105,6 +1137,7 @@ void Engine::register_begin()
 	std::memset(level_hist_, 0, sizeof(level_hist_));
 	cnt_ = Counters{};
 	while (!queue_.empty()) queue_.pop();
+	if (flow_mode()) { ensure_queues(kFlowSearches); flow_reset(); }
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	const float Z[3] = {0, 0, 0};
 	// initial error (jly_goicp.cpp:357-372) and initial ICP (:375-391)
@@ -1139,10 +1172,9 @@ void Engine::register_begin()
 	publish(false);
 }
 
-void Engine::process_parents(const std::vector<Node>& parents)
+// the rotation children of the given parents that survive the pi-ball and range culls (jly_goicp.cpp:427-467)
+void Engine::make_kids(const std::vector<Node>& parents, std::vector<Kid>& kids)
 {
-	struct Child { Node node; float R[9]; };
-	std::vector<Child> kids;
 	for (const Node& parent : parents) {
 		Node c{};
 		c.w = parent.w / 2;          // jly_goicp.cpp:427-428
@@ -1153,53 +1185,66 @@ void Engine::process_parents(const std::vector<Node>& parents)
 			// pi-ball cull (:443): float sqrt, double subtraction and comparison
 			if ((double)std::sqrt(v1 * v1 + v2 * v2 + v3 * v3) - kSQRT3 * (double)c.w / 2 > kPI) continue;
 			if (rot_boxed_ && !in_box(c, rot_lo_, rot_hi_)) continue;     // outside the configured rotation range
-			Child k;
+			Kid k;
 			k.node = c;
+			k.parent_lb = parent.lb;
 			rodrigues(v1, v2, v3, k.R);
 			kids.push_back(k);
 		}
 	}
+}
+
+// jly_goicp.cpp:495-544: the upper-bound search of a rotation child is in; returns true on the early exit (:527)
+bool Engine::handle_ub(Kid& k, const SearchOut& s)
+{
+	cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
+	k.node.ub = s.best;
+	std::memcpy(curR_, k.R, sizeof(curR_));
+	if (s.improved) { curT_[0] = s.best_node.x + s.best_node.w / 2; curT_[1] = s.best_node.y + s.best_node.w / 2; curT_[2] = s.best_node.z + s.best_node.w / 2; }
+	if (!(s.best < opt_err_) || !s.improved) return false;
+	float t[3] = {s.best_node.x + s.best_node.w / 2, s.best_node.y + s.best_node.w / 2, s.best_node.z + s.best_node.w / 2};
+	adopt(s.best, k.R, t);
+	float R[9], ti[3];
+	std::memcpy(R, k.R, sizeof(R)); std::memcpy(ti, t, sizeof(ti));
+	float e = icp_from(R, ti);
+	if (e < opt_err_) adopt(e, R, ti);
+	if (p_.verbose) std::fprintf(stderr, "[goicp] rank %d  error* %.6g (ub %.6g, level %d)\n", rank_, opt_err_, s.best, k.node.l);
+	publish(false);
+	if (opt_err_ < sse_thresh_) { early_exit_ = true; return true; }   // :527
+	std::priority_queue<Node> nq;                                       // :533-543
+	while (!queue_.empty()) {
+		Node n = queue_.top(); queue_.pop();
+		if (n.lb < opt_err_) nq.push(n); else break;
+	}
+	queue_.swap(nq);
+	return false;
+}
+
+// :551-562: the lower-bound search is in
+void Engine::handle_lb(Kid& k, const SearchOut& s)
+{
+	cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
+	if (s.best >= opt_err_) return;
+	if (p_.rot_search_depth > 0 && k.node.l >= p_.rot_search_depth) return;   // depth limit: evaluated, not expanded
+	k.node.lb = s.best;
+	queue_.push(k.node);
+}
+
+void Engine::process_parents(const std::vector<Node>& parents)
+{
+	std::vector<Kid> kids;
+	make_kids(parents, kids);
 	if (kids.empty()) return;
 	std::vector<Rot9> rots(kids.size());
 	for (size_t i = 0; i < kids.size(); i++) std::memcpy(rots[i].r, kids[i].R, sizeof(float) * 9);
 	const Node troot = trans_root_;
-
-	auto handle_ub = [&](Child& k, InnerSearch& s) -> bool {   // jly_goicp.cpp:495-544; returns true on early exit
-		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
-		k.node.ub = s.best;
-		std::memcpy(curR_, k.R, sizeof(curR_));
-		if (s.improved) { curT_[0] = s.best_node.x + s.best_node.w / 2; curT_[1] = s.best_node.y + s.best_node.w / 2; curT_[2] = s.best_node.z + s.best_node.w / 2; }
-		if (!(s.best < opt_err_) || !s.improved) return false;
-		float t[3] = {s.best_node.x + s.best_node.w / 2, s.best_node.y + s.best_node.w / 2, s.best_node.z + s.best_node.w / 2};
-		adopt(s.best, k.R, t);
-		float R[9], ti[3];
-		std::memcpy(R, k.R, sizeof(R)); std::memcpy(ti, t, sizeof(ti));
-		float e = icp_from(R, ti);
-		if (e < opt_err_) adopt(e, R, ti);
-		if (p_.verbose) std::fprintf(stderr, "[goicp] rank %d  error* %.6g (ub %.6g, level %d)\n", rank_, opt_err_, s.best, k.node.l);
-		publish(false);
-		if (opt_err_ < sse_thresh_) { early_exit_ = true; return true; }   // :527
-		std::priority_queue<Node> nq;                                       // :533-543
-		while (!queue_.empty()) {
-			Node n = queue_.top(); queue_.pop();
-			if (n.lb < opt_err_) nq.push(n); else break;
-		}
-		queue_.swap(nq);
-		return false;
-	};
-	auto handle_lb = [&](Child& k, InnerSearch& s) {           // :551-562
-		cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
-		if (s.best >= opt_err_) return;
-		if (p_.rot_search_depth > 0 && k.node.l >= p_.rot_search_depth) return;   // depth limit: evaluated, not expanded
-		k.node.lb = s.best;
-		queue_.push(k.node);
-	};
 	auto fresh = [&](size_t slot, float coeff) {
 		InnerSearch s;
 		s.rot_slot = (int)slot; s.coeff = coeff; s.best = opt_err_;
 		s.pq.push(troot);
 		return s;
 	};
+	auto out = [](const InnerSearch& s) { return SearchOut{s.best, s.improved, s.best_node, s.pops, s.cubes}; };
 
 	if (p_.wide_children) {
 		// every child's upper-bound AND lower-bound search in lock-step: one launch per round covers
@@ -1213,28 +1258,189 @@ void Engine::process_parents(const std::vector<Node>& parents)
 		for (auto& s : lbs) ptr.push_back(&s);
 		run_inner(ptr, rots);
 		for (size_t i = 0; i < kids.size(); i++) {
-			if (handle_ub(kids[i], ubs[i])) return;
-			handle_lb(kids[i], lbs[i]);
+			if (handle_ub(kids[i], out(ubs[i]))) return;
+			handle_lb(kids[i], out(lbs[i]));
 		}
 	} else {
 		for (size_t i = 0; i < kids.size(); i++) {
 			InnerSearch u = fresh(i, 0.f);
 			std::vector<InnerSearch*> p1{&u};
 			run_inner(p1, rots);
-			if (handle_ub(kids[i], u)) return;
+			if (handle_ub(kids[i], out(u))) return;
 			InnerSearch l = fresh(i, rot_coeff(kids[i].node.l));
 			std::vector<InnerSearch*> p2{&l};
 			run_inner(p2, rots);
-			handle_lb(kids[i], l);
+			handle_lb(kids[i], out(l));
 			if (cancel_.load()) return;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Continuous flow (wide mode + device-resident queues): rotation children are admitted in batches but HARVESTED one by
+// one -- a child is handled as soon as both its searches have stopped, its slots are recycled, and the next batch of
+// parents is admitted when the number of running searches falls below a low-water mark, instead of waiting for the
+// slowest search of the batch.  (Lock-step batches ended in ~5 rounds with a handful of active searches each, at the
+// latency floor of three launches; those rounds now carry the next batch's work.)  Any expansion order of a best-first BnB
+// is valid; the searches of a child start from the incumbent at its admission.
+// ------------------------------------------------------------------------------------------------
+void Engine::flow_reset()
+{
+	flights_.clear();
+	free_search_.clear(); free_rot_.clear();
+	for (int i = kFlowSearches - 1; i >= 0; i--) free_search_.push_back(i);
+	for (int i = kFlowSearches / 2 - 1; i >= 0; i--) free_rot_.push_back(i);
+	q_hi_ = 0; q_parity_ = 0; flow_active_ = 0;
+	if (d_qctl_) HIPCHK(hipMemsetAsync(d_qctl_, 0, sizeof(QCtl), stream_));
+	// a slot abandoned in flight (early exit, cancel) must not come back as a live search: an all-zero record is an empty
+	// queue that marks itself done at first touch
+	if (d_qsearch_) HIPCHK(hipMemsetAsync(d_qsearch_, 0, sizeof(QSearch) * cap_qsearch_, stream_));
+}
+
+QParams Engine::queue_params() const
+{
+	QParams qp{};
+	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
+	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
+	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
+	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
+	for (int k = 0; k < 3; k++) { qp.lo[k] = trans_boxed_ ? trans_lo_[k] : 0.f; qp.hi[k] = trans_boxed_ ? trans_hi_[k] : 0.f; }
+	return qp;
+}
+
+// a queue outgrew its slab: every child still in flight is finished through the host queues (from its own incumbent)
+void Engine::flow_fallback()
+{
+	queue_fallbacks_++; cnt_.queue_fallbacks++;
+	std::vector<Flight> todo;
+	for (const Flight& f : flights_) if (!f.handled) todo.push_back(f);
+	flow_reset();
+	for (Flight& f : todo) {
+		std::vector<Rot9> rots(1);
+		std::memcpy(rots[0].r, f.kid.R, sizeof(float) * 9);
+		InnerSearch u, l;
+		u.rot_slot = l.rot_slot = 0; u.coeff = 0.f; l.coeff = rot_coeff(f.kid.node.l); u.best = l.best = f.incumbent;
+		u.pq.push(trans_root_); l.pq.push(trans_root_);
+		std::vector<InnerSearch*> ptr{&u, &l};
+		run_inner_host(ptr, rots);
+		if (handle_ub(f.kid, SearchOut{u.best, u.improved, u.best_node, u.pops, u.cubes})) return;
+		handle_lb(f.kid, SearchOut{l.best, l.improved, l.best_node, l.pops, l.cubes});
+	}
+}
+
+int Engine::flow_step(int max_rot_pops)
+{
+	const double t_begin = now_ms();
+	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
+	const QParams qp = queue_params();
+	ensure_batch(1, kFlowSearches / 2);
+	if (!h_qinit_) {
+		HIPCHK(hipHostMalloc(&h_qinit_, sizeof(QInit) * kFlowSearches));
+		HIPCHK(hipMalloc(&d_qinit_, sizeof(QInit) * kFlowSearches));
+	}
+	int pops = 0;
+	auto unhandled = [&] { size_t n = 0; for (const Flight& f : flights_) n += f.handled ? 0 : 1; return n; };
+	while (!early_exit_ && !cancel_.load()) {
+		// ---- admit the next batch of rotation parents when the running searches are few ----
+		const int P = std::max(1, std::min(p_.rot_batch, rot_ramp_));
+		if (!converged_ && !queue_.empty() && pops < max_rot_pops && flow_active_ <= (flights_.empty() ? kFlowSearches : p_.flow) &&
+		    free_search_.size() >= (size_t)16 * P && free_rot_.size() >= (size_t)8 * P) {
+			std::vector<Node> parents;
+			while ((int)parents.size() < P && !queue_.empty() && pops < max_rot_pops) {
+				const Node parent = queue_.top();
+				if ((opt_err_ - parent.lb) <= sse_thresh_) {      // jly_goicp.cpp:416 -- only final once nothing is in flight
+					if (parents.empty() && unhandled() == 0) { queue_.pop(); cnt_.rot_pops++; pops++; converged_ = true; }
+					break;
+				}
+				queue_.pop();
+				cnt_.rot_pops++;
+				pops++;
+				parents.push_back(parent);
+			}
+			if (!parents.empty()) {
+				rot_ramp_ = std::min(rot_ramp_ * 2, 1 << 20);
+				std::vector<Kid> kids;
+				make_kids(parents, kids);
+				int n = 0;
+				for (Kid& k : kids) {
+					Flight f{};
+					f.kid = k; f.incumbent = opt_err_; f.handled = false;
+					f.rot_slot = free_rot_.back(); free_rot_.pop_back();
+					f.s_ub = free_search_.back(); free_search_.pop_back();
+					f.s_lb = free_search_.back(); free_search_.pop_back();
+					std::memcpy(h_rots_[f.rot_slot].r, k.R, sizeof(float) * 9);
+					h_qinit_[n++] = QInit{f.s_ub, opt_err_, 0.f, f.rot_slot};
+					h_qinit_[n++] = QInit{f.s_lb, opt_err_, rot_coeff(k.node.l), f.rot_slot};
+					q_hi_ = std::max(q_hi_, std::max(f.s_ub, f.s_lb) + 1);
+					flights_.push_back(f);
+				}
+				if (n) {
+					HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * (kFlowSearches / 2), hipMemcpyHostToDevice, stream_));
+					HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * n, hipMemcpyHostToDevice, stream_));
+					HIPCHK(launch_bnb_init_list(d_qsearch_, d_qnodes_, d_qinit_, n, qp, stream_));
+					flow_active_ += n;
+				}
+			}
+		}
+		if (unhandled() == 0) break;
+		// ---- a chunk of rounds over every slot in use ----
+		const double t0 = now_ms();
+		QParams qr = qp;
+		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueMaxPop : (flow_active_ <= 64 ? std::min(kQueueMaxPop, 2 * qp.K) : qp.K);
+		const int max_groups = q_hi_ * qr.K;
+		for (int r = 0; r < 3; r++) {
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qctl_, q_parity_, stream_));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0],
+			                           max_groups, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+			q_parity_ ^= 1;
+			cnt_.bounds_launches++;
+			queue_rounds_++;
+		}
+		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * (size_t)q_hi_, hipMemcpyDeviceToHost, stream_));
+		t_submit_ += now_ms() - t0;
+		const double t1 = now_ms();
+		HIPCHK(hipStreamSynchronize(stream_));
+		t_wait_ += now_ms() - t1;
+		if (h_qctl_->overflow) { flow_fallback(); continue; }
+		// ---- harvest: every child whose two searches have stopped, in admission order ----
+		const double t2 = now_ms();
+		int active = 0;
+		bool stop = false;
+		for (Flight& f : flights_) {
+			if (f.handled) continue;
+			const QSearch& u = h_qsearch_[f.s_ub];
+			const QSearch& l = h_qsearch_[f.s_lb];
+			// a search that has stopped has no pending children: done is only set in the selection phase, after the digest
+			if (!u.done || !l.done) { active += (u.done ? 0 : 1) + (l.done ? 0 : 1); continue; }
+			f.handled = true;
+			free_search_.push_back(f.s_ub); free_search_.push_back(f.s_lb); free_rot_.push_back(f.rot_slot);
+			if (stop) continue;                                                  // early exit taken: the rest is abandoned
+			const SearchOut su{u.best, u.improved != 0, Node{u.bx, u.by, u.bz, u.bw, 0.f, 0.f, 0}, u.pops, u.cubes};
+			const SearchOut sl{l.best, l.improved != 0, Node{l.bx, l.by, l.bz, l.bw, 0.f, 0.f, 0}, l.pops, l.cubes};
+			if (handle_ub(f.kid, su)) { stop = true; continue; }
+			handle_lb(f.kid, sl);
+		}
+		t_collect_ += now_ms() - t2;
+		flow_active_ = active;
+		flights_.erase(std::remove_if(flights_.begin(), flights_.end(), [](const Flight& f) { return f.handled; }), flights_.end());
+		if (flights_.empty()) q_hi_ = 0;
+		publish(false);
+		if (pops >= max_rot_pops && flights_.empty()) break;
+	}
+	return pops;
 }
 
 StepStatus Engine::register_step(int max_rot_pops)
 {
 	DeviceGuard guard(dev_);
 	int pops = 0;
+	if (flow_mode()) {
+		const double icp0 = icp_ms_;
+		pops = flow_step(max_rot_pops);
+		bnb_ms_ -= icp_ms_ - icp0;           // flow_step's clock also ran through the ICP runs it triggered
+		publish(false);
+	} else
 	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
 		// Rotation parents expanded together: ramps 8, 16, 32 ... rot_batch.  Easy registrations end in
 		// the first rounds and pay for little speculation; long searches run with few, large launches
@@ -1260,9 +1466,11 @@ StepStatus Engine::register_step(int max_rot_pops)
 	}
 	StepStatus st{};
 	st.early_exit = early_exit_ ? 1 : 0;
-	st.finished = (early_exit_ || converged_ || queue_.empty() || cancel_.load()) ? 1 : 0;
+	st.finished = (early_exit_ || converged_ || (queue_.empty() && flights_.empty()) || cancel_.load()) ? 1 : 0;
 	st.best_sse = opt_err_;
 	st.frontier_lb = (queue_.empty() || converged_ || early_exit_) ? std::numeric_limits<float>::infinity() : queue_.top().lb;
+	if (!converged_ && !early_exit_)
+		for (const Flight& f : flights_) st.frontier_lb = std::min(st.frontier_lb, f.kid.parent_lb);   // children still in flight stand for their parents
 	st.rot_pops = cnt_.rot_pops;
 	return st;
 }
@@ -1307,7 +1515,7 @@ void Engine::run()
 	double t0 = now_ms();
 	register_begin();
 	while (true) {
-		StepStatus st = register_step(64);
+		StepStatus st = register_step(flow_mode() ? (1 << 20) : 64);     // the flow drains its in-flight searches at the end of a step
 		if (st.finished) break;
 	}
 	register_ms_ = now_ms() - t0;

@@ -31,6 +31,8 @@ struct Params {
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
 	int bounds_fp16 = 0;          // 1: BnB cube bounds read a half-precision copy of the bricked DT (rounded toward zero: lower bounds stay valid, upper bounds low by <= 2^-10 relative); ICP, the DT re-score and trimmed bounds keep the fp32 grid.  Not bit-parity: opt-in
 	int icp_nn_cache = 0;         // 1: an ICP pass skips (exactly) the tree walk of every query whose cached neighbour is provably still the nearest (measured slower on real trajectories, DESIGN 3.6: opt-in); 0: every query walks every pass; bit-identical states either way
+	int flow = 0;                 // opt-in; L > 0: continuous flow over the device queues -- rotation children are harvested one by one and the next batch of parents is admitted when at most this many inner searches still run; 0: lock-step batches
+	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 128 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
@@ -144,6 +146,23 @@ private:
 	bool run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);   // false: a queue overflowed, nothing was changed
 	void ensure_queues(size_t nsearch);
 	void process_parents(const std::vector<Node>& parents);
+	struct Kid { Node node; float R[9]; float parent_lb; };                       // a rotation child and its Rodrigues matrix
+	struct SearchOut { float best; bool improved; Node best_node; long long pops, cubes; };   // what an inner search returns
+	void make_kids(const std::vector<Node>& parents, std::vector<Kid>& kids);
+	bool handle_ub(Kid& k, const SearchOut& s);
+	void handle_lb(Kid& k, const SearchOut& s);
+	// continuous flow of the outer search over the device-resident queues (engine.cpp)
+	static constexpr int kFlowSearches = 2048;     // search slots (two per rotation child in flight)
+	struct Flight { Kid kid; int rot_slot, s_ub, s_lb; float incumbent; bool handled; };
+	bool flow_mode() const { return p_.device_queues && p_.wide_children && p_.trans_batch > 1 && p_.flow; }
+	int flow_step(int max_rot_pops);
+	void flow_reset();
+	void flow_fallback();
+	QParams queue_params() const;
+	std::vector<Flight> flights_;
+	std::vector<int> free_search_, free_rot_;
+	int q_hi_ = 0, q_parity_ = 0, flow_active_ = 0;
+	QInit* h_qinit_ = nullptr; QInit* d_qinit_ = nullptr;
 	void adopt(float err, const float R[9], const float t[3]);
 	float icp_from(float R[9], float t[3]);
 	void publish(bool finished);

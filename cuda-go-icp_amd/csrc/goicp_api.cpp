@@ -112,7 +112,7 @@ void goicp_params_default(goicp_params* p)
 		p->trans_min[k] = d.trans_min[k]; p->trans_max[k] = d.trans_max[k];
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
-	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->icp_nn_cache = d.icp_nn_cache; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
+	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->icp_nn_cache = d.icp_nn_cache; p->flow = d.flow; p->adaptive_k = d.adaptive_k; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -155,7 +155,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 				p.trans_min[k] = params->trans_min[k]; p.trans_max[k] = params->trans_max[k];
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
-			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.icp_nn_cache = params->icp_nn_cache; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
+			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.icp_nn_cache = params->icp_nn_cache; p.flow = params->flow; p.adaptive_k = params->adaptive_k; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }

@@ -122,6 +122,13 @@ typedef struct goicp_params {
 	                          * and a lower bound s on the distance from q_ref to every OTHER target point (a 2-nearest walk); at a later
 	                          * position q the walk is skipped whenever |q - m| + |q - q_ref| < s, which proves m is still THE nearest
 	                          * neighbour -- exact, not approximate; 0: every query walks the tree in every pass (bit-identical results) */
+	int32_t flow;            /* opt-in (default 0 = lock-step batches: every rotation batch runs until its slowest inner search has stopped).
+	                          * L > 0: continuous flow of the outer search over the device queues -- a rotation child is handled as soon as
+	                          * both its inner searches have stopped, and the next rotation parents are admitted when at most L searches
+	                          * still run.  Same bounds and prune rules, same optimum; more speculative work -- faster or slower depending
+	                          * on which candidate happens to be refined first */
+	int32_t adaptive_k;      /* 1 (default): when few inner searches are still running (the stragglers of a batch) each may expand up to 128
+	                          * nodes per round instead of trans_batch: fewer latency-bound rounds; 0: always trans_batch */
 	int32_t queue_cap;       /* test hook: nodes a device-resident queue may hold before its batch is re-run through the host queues
 	                          * (0 = the full 8 192-node slab) */
 	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner

@@ -943,6 +943,43 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
         r.close()
 
 
+def test_queue_round_width_and_continuous_flow(pkg, bunny_model, bunny_data10):
+    """The two driver options above the device queues.  (1) The round width: a search may expand up to 128 nodes per
+    round (trans_batch = 128 directly; adaptive_k widens the stragglers of a batch from 32 to 64 / 128) -- more
+    speculation, same bounds, same stop rule, so every width reproduces the reference's InnerBnB values
+    (tests/golden/inner_bnb.json) to within SSEThresh.  (2) flow > 0 (opt-in): rotation children are handled as their
+    inner searches stop and new parents are admitted while others still run -- the same prune rules in another order,
+    so the registration ends at the reference's optimum as well, including through the overflow fallback."""
+    g = golden("inner_bnb")
+    regs = {w: pkg.Registration(bunny_model, bunny_data10, 1e-3, trans_batch=w, adaptive_k=ak) for w, ak in ((128, 0), (64, 0), (32, 1), (32, 0), (8, 1))}
+    thr = float(regs[32].sse_threshold)
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for full in case["full"]:
+            cubes = {}
+            for w, reg in regs.items():
+                v, node, c = reg.inner_bnb(R, full["level"], full["incumbent"])
+                assert abs(v - full["value"]) <= thr, (w, v, full["value"])
+                assert c.queue_fallbacks == 0
+                cubes[w] = c.cubes
+            assert cubes[8] <= cubes[128] <= 16 * max(cubes[8], 64)         # wider rounds speculate more, never less
+    for r in regs.values():
+        r.close()
+    ge = golden("e2e_bunny10")
+    for kw in (dict(flow=4), dict(flow=48), dict(flow=16, adaptive_k=0), dict(flow=8, queue_cap=48), dict(flow=0, adaptive_k=0)):
+        e = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, **kw)
+        e.run()
+        assert e.get_best_error() <= 1.02 * ge["sse"] and e.get_best_error() < ge["sse_threshold"], kw
+        assert rot_angle(e.optR, np.array(ge["R"])) <= 3e-2, kw
+        assert e.counters.bounds_launches > 0
+        if "queue_cap" in kw:
+            assert e.counters.queue_fallbacks >= 1
+        # a second run of the same engine starts from a clean flow state
+        e.run()
+        assert e.get_best_error() <= 1.02 * ge["sse"], kw
+        e.registration.close()
+
+
 def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
     """SURVEY 8(e) with the protocol inside the library (csrc/shard.cpp through goicp_register_sharded): (i) RCCL at
     world 1 -- ncclAllReduce(MIN) of the packed words and ncclBroadcast really execute on this GPU (a one-GPU box cannot

@@ -30,6 +30,33 @@ elif which == "ksweep":
                 best = min(best, dt) if best else dt
                 eng.registration.close()
             print("K=%d rot_batch=%d: best %.4fs sse %.4f trans_pops %d cubes %d launches %d" % (K, rb, best, eng.get_best_error() if False else 0, c.trans_pops, c.cubes, c.bounds_launches), flush=True)
+elif which == "flowsweep":
+    from cuda_go_icp_amd import synth
+    cases = {"bunny": (cloud("model_bunny"), cloud("data_bunny"), 1e-3, 300), "bunny10": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, 300),
+             "spanner": (cloud("spanner_target"), cloud("spanner_source"), 1e-4, 300), "s1": synth.make_pair(**{k: synth.S1[k] for k in ("seed", "M", "N")})[:2] + (1e-4, 300)}
+    sk = cloud("skull_scan"); rng = np.random.default_rng(1234); sub = sk[rng.random(len(sk)) < 0.3].astype(np.float64)
+    cx, sx, cy, sy, cz, sz = np.cos(1.3), np.sin(1.3), np.cos(-0.7), np.sin(-0.7), np.cos(2.1), np.sin(2.1)
+    Rg = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    cases["skull"] = (sk, ((sub - np.array([0.15, -0.10, 0.05])) @ Rg + rng.normal(scale=1e-3, size=sub.shape)).astype(np.float32), 1e-3, 300)
+    t2, s2, _, _ = synth.make_pair(seed=synth.S2["seed"], M=1000000, N=1000000, amp=0.15)
+    cases["s2amp.15"] = (t2, s2, 1.2 * 6.05e-6, 512)
+    for name, (tg, sr, mse, V) in cases.items():
+        for fl, ak in ((0, 0), (0, 1), (4, 0), (4, 1), (16, 1), (48, 1)):
+            best = None
+            for rep in range(2):
+                eng = pkg.FastGoICP(tg, sr, mse, flow=fl, dt_size=V, adaptive_k=ak)
+                t1 = time.time(); eng.run(); dt = time.time() - t1; c = eng.counters
+                best = min(best, dt) if best else dt
+                sse = eng.get_best_error(); eng.registration.close()
+            print("%-9s flow=%-3d ak=%d best %.4fs sse %.4f rot_pops %d cubes %d rounds %d icp %d" % (name, fl, ak, best, sse, c.rot_pops, c.cubes, c.bounds_launches, c.icp_iters), flush=True)
+elif which == "flow":
+    for fl in (1, 0, 1, 0):
+        for K in (32, 16):
+            eng = pkg.FastGoICP(cloud("model_bunny"), cloud("data_bunny"), 1e-3, verbose=1 if K == 32 else 0, flow=fl, trans_batch=K)
+            t1 = time.time(); eng.run(); c = eng.counters
+            print("bunny flow=%d K=%d run %.4fs sse %.4f rot_pops %d trans_pops %d cubes %d launches %d icp %d" % (
+                fl, K, time.time() - t1, eng.get_best_error(), c.rot_pops, c.trans_pops, c.cubes, c.bounds_launches, c.icp_iters), flush=True)
+            eng.registration.close()
 elif which == "ramp":
     for ramp in (4, 8, 16, 32, 64):
         for rb in (32, 64, 128, 256):

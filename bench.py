@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
                     help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded end-to-end registration when N > 1")
+    ap.add_argument("--sharded-timeout", type=int, default=150, help="watchdog of the sharded leg, seconds")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL; one GPU per rank) | gloo (rehearsal: all ranks on GPU 0)")
     args = ap.parse_args()
 
@@ -264,54 +265,6 @@ def main():
         if world > 1:
             dist.all_reduce(er, op=dist.ReduceOp.MAX)
         repeats.append(world * Bc * args.steps / float(er.item()))
-
-    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the
-    # best error + winner's pose between steps) on a noisy synthetic pair -- BASELINE configs[3]'s
-    # problem class (its spanner scans cannot travel) ----
-    sharded_res = None
-    if world > 1 and not args.no_sharded:
-        try:
-            from cuda_go_icp_amd import sharded, synth
-            tgt, srcc, Rgt, tgt_t = synth.make_pair(seed=synth.S1["seed"], M=40000, N=40000, noise=0.01)
-            eng = pkg.FastGoICP(tgt, srcc, 1e-3, dt_size=300, device=local_rank)
-            # the exchange runs inside the library (csrc/shard.cpp) over its own RCCL communicator (csrc/rccl_comm.cpp):
-            # rank 0 makes the ncclUniqueId, torch.distributed only carries those 128 bytes to the other ranks
-            if args.backend == "nccl":
-                ident = C.create_string_buffer(128)
-                if rank == 0:
-                    B.check(lib.goicp_rccl_unique_id(ident))
-                idt = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
-                dist.broadcast(idt, src=0)
-                ident = C.create_string_buffer(bytes(idt.cpu().tolist()), 128)
-                comm = B.CCommOps()
-                B.check(lib.goicp_rccl_comm_create(ident, rank, world, local_rank, C.byref(comm)))
-                exchange = "library protocol over RCCL (ncclAllReduce MIN of 5 packed u64 + ncclBroadcast of R|t on change + rebalancing)"
-            else:
-                comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
-                exchange = "library protocol over torch.distributed gloo (rehearsal)"
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=4)
-            wall = time.perf_counter() - t1
-            sse, Rr, tr = eng.pose()
-            Rr = Rr.reshape(3, 3)
-            stats = {"exchanges": lstats["exchanges"], "donations": lstats["donations"], "broadcasts": lstats["broadcasts"], "exchange": exchange}
-            if args.backend == "nccl":
-                B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
-            c = eng.counters
-            tot = torch.tensor([float(c.cubes), float(c.rot_pops), wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
-            sharded_res = {"workload": "synthetic S1 surface, N=M=40000, noise sigma 0.01 (spanner_goicp class), DT 300^3",
-                           "wall_s": round(wall, 4), "sse": float(sse), "cube_bounds_all_ranks": int(tot[0].item()),
-                           "rot_pops_all_ranks": int(tot[1].item()), "exchanges": stats["exchanges"], "pose_broadcasts": stats["broadcasts"],
-                           "donations": stats["donations"], "exchange": stats["exchange"],
-                           "rot_error_rad": round(ang, 5), "trans_error": round(float(np.linalg.norm(tr - tgt_t)), 5)}
-            eng.registration.close()
-        except Exception as e:      # reported, never fatal for the headline line
-            sharded_res = {"error": repr(e)}
 
     # ---- ICP iterations/s: the loop does not shard, so N GPUs run N replicas side by side ----
     icp = None
@@ -494,9 +447,81 @@ def main():
                           "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) best ub" if world > 1 else "local min"},
                "value_repeats": {"n": len(repeats), "min": round(min(repeats), 1), "max": round(max(repeats), 1),
                                  "spread_pct": round(100 * (max(repeats) - min(repeats)) / value, 2)},
-               "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": sharded_res}
-        print(json.dumps(out), flush=True)
+               "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": None}
     reg.close()
+
+    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the
+    # best error + winner's pose between steps) on a noisy synthetic pair -- BASELINE configs[3]'s
+    # problem class (its spanner scans cannot travel) ----
+    sharded_res = None
+    sharded_hung = False
+    if world > 1 and not args.no_sharded:
+        box = {}
+
+        def sharded_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                from cuda_go_icp_amd import sharded, synth
+                tgt, srcc, Rgt, tgt_t = synth.make_pair(seed=synth.S1["seed"], M=40000, N=40000, noise=0.01)
+                eng = pkg.FastGoICP(tgt, srcc, 1e-3, dt_size=300, device=local_rank)
+                # the exchange runs inside the library (csrc/shard.cpp) over its own RCCL communicator (csrc/rccl_comm.cpp):
+                # rank 0 makes the ncclUniqueId, torch.distributed only carries those 128 bytes to the other ranks
+                if args.backend == "nccl":
+                    ident = C.create_string_buffer(128)
+                    if rank == 0:
+                        B.check(lib.goicp_rccl_unique_id(ident))
+                    idt = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+                    dist.broadcast(idt, src=0)
+                    ident = C.create_string_buffer(bytes(idt.cpu().tolist()), 128)
+                    comm = B.CCommOps()
+                    B.check(lib.goicp_rccl_comm_create(ident, rank, world, local_rank, C.byref(comm)))
+                    exchange = "library protocol over RCCL (ncclAllReduce MIN of 5 packed u64 + ncclBroadcast of R|t on change + rebalancing)"
+                else:
+                    comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
+                    exchange = "library protocol over torch.distributed gloo (rehearsal)"
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=4)
+                wall = time.perf_counter() - t1
+                sse, Rr, tr = eng.pose()
+                Rr = Rr.reshape(3, 3)
+                stats = {"exchanges": lstats["exchanges"], "donations": lstats["donations"], "broadcasts": lstats["broadcasts"], "exchange": exchange}
+                if args.backend == "nccl":
+                    B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
+                c = eng.counters
+                tot = torch.tensor([float(c.cubes), float(c.rot_pops), wall], dtype=torch.float64, device=dev)
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
+                box['res'] = {"workload": "synthetic S1 surface, N=M=40000, noise sigma 0.01 (spanner_goicp class), DT 300^3",
+                               "wall_s": round(wall, 4), "sse": float(sse), "cube_bounds_all_ranks": int(tot[0].item()),
+                               "rot_pops_all_ranks": int(tot[1].item()), "exchanges": stats["exchanges"], "pose_broadcasts": stats["broadcasts"],
+                               "donations": stats["donations"], "exchange": stats["exchange"],
+                               "rot_error_rad": round(ang, 5), "trans_error": round(float(np.linalg.norm(tr - tgt_t)), 5)}
+                eng.registration.close()
+            except Exception as e:      # reported, never fatal for the headline line
+                box['res'] = {"error": repr(e)}
+
+        # the leg runs under a watchdog: the library's own RCCL collectives have no timeout, and a rank that never arrives
+        # must cost this bench its sharded figure, not its headline line
+        import threading
+        th = threading.Thread(target=sharded_leg, daemon=True)
+        th.start()
+        th.join(args.sharded_timeout)
+        if th.is_alive():
+            sharded_hung = True
+            sharded_res = {"error": "no result within %d s (watchdog)" % args.sharded_timeout}
+        else:
+            sharded_res = box.get('res')
+
+    if rank == 0:
+        out["e2e_sharded"] = sharded_res
+        print(json.dumps(out), flush=True)
+    if sharded_hung:
+        # a rank is still inside a collective that will never complete: the line is out, leave without the teardown
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1107,7 +1107,9 @@ float Engine::icp_from(float R[9], float t[3])
 	// GoICP::ICP (jly_goicp.cpp:93-132): ICP3D::Run, then re-score with the DT
 	int it = 0;
 	icp_run(R, t, p_.icp_max_iter, icp_err_diff_, &it);
-	return eval_sse(R, t);
+	const float e = eval_sse(R, t);
+	if (p_.verbose > 1) std::fprintf(stderr, "[goicp] ICP run: %d iterations, %.2f ms, error %.6g (rot pops so far %lld, cube bounds %lld)\n", it, now_ms() - t0, e, cnt_.rot_pops, cnt_.cubes);
+	return e;
 }
 
 void Engine::offer_global_best(float sse, const float R[9], const float t[3])

@@ -11,6 +11,7 @@
 // over N points.  Any expansion order of a best-first BnB yields valid bounds; with trans_batch = 1
 // and wide_children = 0 the visit order is exactly the reference's.
 #include "engine.hpp"
+#include "trace.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -126,9 +127,16 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	for (size_t i = 0; i < 3 * M; i++) if (!std::isfinite(target[i])) throw std::invalid_argument("goicp: non-finite coordinate in the target cloud");
 	for (size_t i = 0; i < 3 * N; i++) if (!std::isfinite(source[i])) throw std::invalid_argument("goicp: non-finite coordinate in the source cloud");
 	double t_mark = now_ms();
+	TraceRange tr_create("goicp:create");
+	static const char* const kStages[] = {"goicp:create:device_setup", "goicp:create:source_order_upload", "goicp:create:distance_transform",
+	                                      "goicp:create:kd_hierarchy", "goicp:create:staging_buffers", "goicp:create:end"};
+	int stage = 0;
+	Trace::get().push(kStages[0]);
+	struct PopLast { ~PopLast() { Trace::get().pop(); } } pop_last;     // the stage range open when init returns or throws
 	auto lap = [&](const char* what) {
 		if (p_.verbose) std::fprintf(stderr, "[goicp] create: %-28s %8.2f ms\n", what, now_ms() - t_mark);
 		t_mark = now_ms();
+		if (Trace::get().on()) { Trace::get().pop(); stage = std::min(stage + 1, 5); Trace::get().push(kStages[stage]); }
 	};
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -886,6 +894,7 @@ void Engine::ensure_queues(size_t nsearch)
 // looks at one word every few rounds.  Same bounds, same stop and prune rules as run_inner_host.
 bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
 {
+	TraceRange tr("goicp:inner_bnb_rounds");
 	const size_t S = searches.size(), nrot = rots.size();
 	const int K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
 	ensure_queues(S);
@@ -1102,6 +1111,7 @@ void Engine::adopt(float err, const float R[9], const float t[3])
 
 float Engine::icp_from(float R[9], float t[3])
 {
+	TraceRange tr("goicp:icp_run+rescore");
 	const double t0 = now_ms();
 	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{icp_ms_, t0};
 	// GoICP::ICP (jly_goicp.cpp:93-132): ICP3D::Run, then re-score with the DT
@@ -1234,6 +1244,7 @@ void Engine::handle_lb(Kid& k, const SearchOut& s)
 
 void Engine::process_parents(const std::vector<Node>& parents)
 {
+	TraceRange tr("goicp:rotation_batch");
 	std::vector<Kid> kids;
 	make_kids(parents, kids);
 	if (kids.empty()) return;
@@ -1332,6 +1343,7 @@ void Engine::flow_fallback()
 
 int Engine::flow_step(int max_rot_pops)
 {
+	TraceRange tr("goicp:flow_step");
 	const double t_begin = now_ms();
 	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
 	const QParams qp = queue_params();
@@ -1514,6 +1526,7 @@ void Engine::register_end()
 void Engine::run()
 {
 	DeviceGuard guard(dev_);
+	TraceRange tr("goicp:register");
 	double t0 = now_ms();
 	register_begin();
 	while (true) {

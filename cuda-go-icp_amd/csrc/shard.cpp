@@ -21,6 +21,7 @@
 //     a world-sized vector) and each idle rank receives, by broadcast from the currently largest queue, every second
 //     cube of that queue in priority order (at most kDonateMax) -- both sides keep cubes of every priority.
 #include "../../include/goicp_mi355.h"
+#include "trace.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -82,7 +83,10 @@ int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, i
 		w[2] = ss.early_exit ? 0u : 1u;
 		w[3] = ss.finished ? 1u : 0u;
 		w[4] = ss.finished ? 0u : 1u;
-		rc = comm->allreduce_min_u64(comm->ctx, w, 5);
+		{
+			TraceRange tr("goicp:exchange");
+			rc = comm->allreduce_min_u64(comm->ctx, w, 5);
+		}
 		if (rc != GOICP_OK) return rc;
 		st.exchanges++;
 		const float gbest = from_orderable((uint32_t)(w[0] >> 32));

@@ -1267,8 +1267,10 @@ void Engine::process_parents(const std::vector<Node>& parents)
 		ubs.reserve(kids.size()); lbs.reserve(kids.size());
 		for (size_t i = 0; i < kids.size(); i++) { ubs.push_back(fresh(i, 0.f)); lbs.push_back(fresh(i, rot_coeff(kids[i].node.l))); }
 		std::vector<InnerSearch*> ptr;
-		for (auto& s : ubs) ptr.push_back(&s);
-		for (auto& s : lbs) ptr.push_back(&s);
+		// a child's two searches side by side: they share the rotation, expand the same root and a third of the same
+		// depth-1 nodes in the same rounds, and the bound kernel walks the expansions in search order -- the second of the
+		// pair finds the first one's DT lines in L2 (shallow rounds are bound by compulsory line fetches)
+		for (size_t i = 0; i < kids.size(); i++) { ptr.push_back(&ubs[i]); ptr.push_back(&lbs[i]); }
 		run_inner(ptr, rots);
 		for (size_t i = 0; i < kids.size(); i++) {
 			if (handle_ub(kids[i], out(ubs[i]))) return;

@@ -664,7 +664,10 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 // Exactness: box lower bounds use the same monotone float accumulation as the point distances and
 // the boxes are exact, ties go to the lowest original index -> identical to a brute-force scan.
 // ------------------------------------------------------------------------------------------------
-constexpr int kIcpThreads = 256;     // 4 wavefronts = 16 queries per workgroup
+#ifndef GOICP_ICP_THREADS
+#define GOICP_ICP_THREADS 256
+#endif
+constexpr int kIcpThreads = GOICP_ICP_THREADS;     // 4 wavefronts = 16 queries per workgroup
 
 // Upper bound on the NN distance from the distance transform.  For ANY voxel v:
 //   d(q, NN) <= |q - centre(v)| + DT[v] + sqrt(3)/2 voxel
@@ -942,7 +945,7 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 // the exact skip test of rows_nearest<TWO>'s comment; entries never go stale (they are statements about the static
 // target cloud), an entry with sqrt(best2_ref) = 0 (fresh engine, tied neighbours) always walks.
 template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2>
-__global__ __launch_bounds__(kIcpThreads, 8) void icp_pass_kernel(const float4* __restrict__ src, int N,
+__global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                   IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                                   float* __restrict__ partials, int* __restrict__ ticket,
                                                                   float4* __restrict__ nn_cache, int* __restrict__ hit_counter)

@@ -602,6 +602,30 @@ def test_cli_end_to_end(pkg, tmp_path):
     assert bad.returncode == 1 and "error" in bad.stderr.lower()
 
 
+def test_cli_with_roctx_ranges(pkg, tmp_path):
+    """GOICP_ROCTX=1 (csrc/trace.hpp): the engine looks the roctx library up with dlopen and brackets its phases; with or
+    without a profiler attached, with or without the library, the registration is the same."""
+    import subprocess
+    from conftest import ROOT
+    for name in ("model_rand", "data_rand"):
+        pts = cloud(name)
+        with open(tmp_path / (name + ".txt"), "w") as f:
+            f.write("%d\n" % len(pts))
+            for q in pts:
+                f.write("%.9g %.9g %.9g\n" % tuple(q))
+    sses = []
+    for tag, env in (("off", {}), ("on", {"GOICP_ROCTX": "1"})):
+        out_toml = tmp_path / ("output_%s.toml" % tag)
+        (tmp_path / "cfg.toml").write_text(
+            '[info]\ndescription = "roctx test"\n[io]\ntarget = "model_rand.txt"\nsource = "data_rand.txt"\n'
+            'output = "%s"\nvisualization = "%s"\n[params]\nmode = 4\nsubsample = 1.0\nmse_threshold = 1e-3\nresize = 1.0\n'
+            % (out_toml, tmp_path / "viz.ply"))
+        exe = os.path.join(ROOT, "cuda-go-icp_amd", "goicp_cli")
+        subprocess.run([exe, str(tmp_path / "cfg.toml")], check=True, capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        sses.append(float([l for l in out_toml.read_text().splitlines() if l.startswith("sse =")][0].split("=")[1]))
+    assert sses[0] == sses[1]
+
+
 # ----------------------------------------------------------------------------------------------
 # device-side k-d tree build (SURVEY 8f-4)
 # ----------------------------------------------------------------------------------------------

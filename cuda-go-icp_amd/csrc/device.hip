@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <climits>
+#include <cstdlib>
 #include <cmath>
 
 #include "device.hpp"
@@ -667,6 +668,10 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 #ifndef GOICP_ICP_THREADS
 #define GOICP_ICP_THREADS 256
 #endif
+// up to this many source points the pass deals strangers, not neighbours, to a wavefront (icp_pass_kernel).  Measured, iterations/s
+// neighbours | strangers: bunny 30 k 26.7 k | 29.0 k; synthetic 40 k 16.4 k | 16.5 k; 100 k 8.6 k | 7.5 k; spanner 150 k 12.6 k | 11.7 k;
+// 250 k 4.2 k | 3.3 k; 500 k 2.06 k | 1.45 k
+constexpr int kIcpStridedMaxN = 40000;
 constexpr int kIcpThreads = GOICP_ICP_THREADS;     // 4 wavefronts = 16 queries per workgroup
 
 // Upper bound on the NN distance from the distance transform.  For ANY voxel v:
@@ -944,7 +949,7 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 // nn_cache (two float4 per source point: {q_ref.xyz, sqrt(best2_ref)}, {neighbour xyz, its original index}) != nullptr:
 // the exact skip test of rows_nearest<TWO>'s comment; entries never go stale (they are statements about the static
 // target cloud), an entry with sqrt(best2_ref) = 0 (fresh engine, tied neighbours) always walks.
-template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2>
+template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2, bool STRIDED = false>
 __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                   IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                                   float* __restrict__ partials, int* __restrict__ ticket,
@@ -953,8 +958,14 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 	__shared__ FinScratch sh;
 	float (*red)[kIcpAcc] = sh.red;                                   // [16 rows of the workgroup][16 sums]
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, l = lane & 15;
-	const int i = (blockIdx.x * (kIcpThreads / 64) + wave) * 4 + row;
-	const bool valid = i < N;
+	// Which four queries a wavefront walks.  Neighbours in the k-d order (large clouds: their walks touch the same boxes
+	// and leaves, and at 1 M points the pass is throughput-bound: 926 vs 583 iterations/s) -- or, STRIDED, four queries a
+	// quarter of the cloud apart (small clouds: the pass lasts as long as its slowest wavefront; far-from-surface queries
+	// come in neighbourhoods, so with neighbours in one wavefront all four rows walk long and in different stages, with
+	// strangers the one long walk of a wavefront runs alone: bunny 27.3 k -> 29.7 k iterations/s)
+	const int nw = (N + 3) >> 2, wv = blockIdx.x * (kIcpThreads / 64) + wave;
+	const int i = STRIDED ? wv + row * nw : wv * 4 + row;
+	const bool valid = wv < nw && i < N;
 	const Box6x4 rootb = load_child_boxes4(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
 	const int ic = valid ? i : N - 1;
 	const float4 p = src[ic];
@@ -1684,11 +1695,13 @@ static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& 
 {
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
 	if (nn_cache) {
-		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		if (!FUSED && dt.layout && N <= kIcpStridedMaxN) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 	} else {
 		// four leaves per scan step (S2 845 -> 926 iterations/s, S1 21.9 k -> 23.0 k, bunny 27.0 k -> 27.1 k)
-		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		if (!FUSED && dt.layout && N <= kIcpStridedMaxN) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, false, 4, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 	}
 }

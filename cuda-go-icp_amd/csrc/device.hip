@@ -939,9 +939,9 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 // Workgroup-shared state of one ICP iteration: the per-wavefront sums of the pass and the finalize's scratch, in ONE
 // __shared__ object (a second one beside it can make the compiler drain the memory pipeline before LDS reads).
 constexpr int kFinThreads = 1024;                  // the stand-alone finalize: 256 row streams x four float4 columns
-struct FinScratch { double wsum[kFinThreads / 64][kIcpAcc]; double sums[kIcpAcc]; float red[kIcpThreads / 16][kIcpAcc]; int last; };   // red: one row of sums per 16-lane row
+struct FinScratch { double wsum[kFinThreads / 64][kIcpAcc]; double sums[kIcpAcc]; float red[kIcpThreads / 16][kIcpAcc]; int last; IcpState st; };   // red: one row of sums per 16-lane row
 template <int T> __device__ __forceinline__ void finalize_reduce(const float* __restrict__ partials, int nblocks, FinScratch& sh);
-__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, int lane);
+__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, const IcpState& rd, int lane);
 
 // FUSED: the workgroup that arrives last (one ticket per launch; agent-scope release before the ticket, acquire
 // after it -- cdna_hip_programming.md Guideline 16, counter form) also runs the finalize, so an ICP iteration is ONE
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 		__syncthreads();
 		if (!sh.last) return;
 		finalize_reduce<kIcpThreads>(partials, (int)gridDim.x, sh);
-		if (threadIdx.x < 64) finalize_rows(sh.sums, st, (int)threadIdx.x);
+		if (threadIdx.x < 64) finalize_rows(sh.sums, st, *st, (int)threadIdx.x);
 	}
 }
 
@@ -1418,7 +1418,16 @@ __device__ __forceinline__ void finalize_reduce(const float* __restrict__ partia
 // what lets the correspondence pass carry this code without losing occupancy.
 __device__ __forceinline__ double lane_get(double x, int j) { return __shfl(x, j, 64); }
 __device__ __forceinline__ float lane_getf(float x, int j) { return __shfl(x, j, 64); }
-__device__ __forceinline__ double sum3(double x) { return (lane_get(x, 0) + lane_get(x, 1)) + lane_get(x, 2); }
+// lane J of the wavefront, J a constant: two v_readlane_b32 into scalar registers instead of two ds_bpermute_b32 through
+// the LDS crossbar (a Jacobi rotation takes three such sums; measured: Kabsch 3.7 -> 2.x us per iteration)
+template <int J>
+__device__ __forceinline__ double lane_const(double x)
+{
+	const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, J), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), J);
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double sum3(double x) { return (lane_const<0>(x) + lane_const<1>(x)) + lane_const<2>(x); }
 
 // rows of H in (b0, b1, b2) on lanes 0..2 -> row of the Kabsch rotation in r[3] (same algorithm as kabsch_rotation_dev)
 __device__ __forceinline__ void kabsch_rows(double b0, double b1, double b2, int row, float r[3])
@@ -1490,29 +1499,31 @@ __device__ __forceinline__ void kabsch_rows(double b0, double b1, double b2, int
 }
 
 // called by every lane of ONE wavefront (lanes >= 3 shadow lane 2 and write nothing)
-__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, int lane)
+// state: where the new pose is written; rd: where the old one is read -- the stand-alone finalize hands in a copy its threads
+// fetched into LDS beside the partial rows (one round trip instead of a chain of four behind the branches below)
+__device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, IcpState* __restrict__ state, const IcpState& rd, int lane)
 {
 	const int a = lane < 3 ? lane : 2;
 	const bool writer = lane < 3;
 	const float err_new = (float)sums[15];
-	const int passes = state->passes + 1;
-	if (state->frozen) {                                                     // timing / scoring only
+	const int passes = rd.passes + 1;
+	if (rd.frozen) {                                                     // timing / scoring only
 		if (lane == 0) { state->err_new = err_new; state->passes = passes; }
 		return;
 	}
-	const float err = state->err;
-	if (err > 0.f && err - err_new < state->err_diff_n) {                    // jly_icp3d.hpp:255
+	const float err = rd.err;
+	if (err > 0.f && err - err_new < rd.err_diff_n) {                    // jly_icp3d.hpp:255
 		if (lane == 0) { state->err_new = err_new; state->passes = passes; state->converged = 1; }
 		return;
 	}
-	const double nn = (double)state->n;
-	const float cq = state->cq[a], cm = state->cm[a];
-	const bool carry = state->carry_means != 0;
+	const double nn = (double)rd.n;
+	const float cq = rd.cq[a], cm = rd.cm[a];
+	const bool carry = rd.carry_means != 0;
 	const double sum_q = sums[a] + nn * (double)cq;
 	const double sum_m = sums[3 + a] + nn * (double)cm;
 	// jly_icp3d.hpp:244-263: the reference accumulates on top of the previous means and divides by n
-	const double carry_d = carry ? (double)state->mu_d[a] : 0.0;
-	const double carry_m = carry ? (double)state->mu_m[a] : 0.0;
+	const double carry_d = carry ? (double)rd.mu_d[a] : 0.0;
+	const double carry_m = carry ? (double)rd.mu_m[a] : 0.0;
 	const float mu_d = (float)((carry_d + sum_q) / nn);
 	const float mu_m = (float)((carry_m + sum_m) / nn);
 	const double alpha = (double)mu_d - (double)cq, beta = (double)mu_m - (double)cm;
@@ -1526,9 +1537,9 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 	kabsch_rows(h[0], h[1], h[2], a, Rrow);
 	float oldR[9], oldt[3], sc[3];
 #pragma unroll
-	for (int k = 0; k < 9; k++) oldR[k] = state->R[k];
+	for (int k = 0; k < 9; k++) oldR[k] = rd.R[k];
 #pragma unroll
-	for (int k = 0; k < 3; k++) { oldt[k] = state->t[k]; sc[k] = state->src_centroid[k]; }
+	for (int k = 0; k < 3; k++) { oldt[k] = rd.t[k]; sc[k] = rd.src_centroid[k]; }
 	float acc = 0.f;
 #pragma unroll
 	for (int k = 0; k < 3; k++) acc += Rrow[k] * lane_getf(mu_d, k);
@@ -1546,7 +1557,7 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 	for (int k = 0; k < 3; k++) s3 += Rrow[k] * oldt[k];
 	const float tn = s3 + t_;                                                // t <- R_ t + t_
 	const float cq_new = Rn[0] * sc[0] + Rn[1] * sc[1] + Rn[2] * sc[2] + tn;
-	const int iters = state->iters + 1;
+	const int iters = rd.iters + 1;
 	if (writer) {
 		state->R[3 * a] = Rn[0]; state->R[3 * a + 1] = Rn[1]; state->R[3 * a + 2] = Rn[2];
 		state->t[a] = tn; state->cq[a] = cq_new; state->mu_d[a] = mu_d; state->mu_m[a] = mu_m;
@@ -1572,9 +1583,13 @@ __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* 
                                                                    IcpState* __restrict__ state)
 {
 	__shared__ FinScratch sh;
+	// the loop state travels to LDS in the same round trip as the flag (one word per thread; finalize_reduce's barriers
+	// publish it): finalize_rows then reads it without the chain of dependent global loads its branches would make
+	static_assert(sizeof(IcpState) % 4 == 0 && sizeof(IcpState) / 4 <= kFinThreads, "one word per thread");
+	if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<unsigned*>(&sh.st)[threadIdx.x] = reinterpret_cast<const unsigned*>(state)[threadIdx.x];
 	if (state->converged) return;                 // uniform; the pass kernel left the partials untouched
 	finalize_reduce<kFinThreads>(partials, nblocks, sh);
-	if (threadIdx.x < 64) finalize_rows(sh.sums, state, (int)threadIdx.x);
+	if (threadIdx.x < 64) finalize_rows(sh.sums, state, sh.st, (int)threadIdx.x);
 }
 
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane

@@ -671,7 +671,7 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 // up to this many source points the pass deals strangers, not neighbours, to a wavefront (icp_pass_kernel).  Measured, iterations/s
 // neighbours | strangers: bunny 30 k 26.7 k | 29.0 k; synthetic 40 k 16.4 k | 16.5 k; 100 k 8.6 k | 7.5 k; spanner 150 k 12.6 k | 11.7 k;
 // 250 k 4.2 k | 3.3 k; 500 k 2.06 k | 1.45 k
-constexpr int kIcpStridedMaxN = 40000;
+// (kIcpStridedMaxN lives in device.hpp: the engine sizes the accumulators by it)
 constexpr int kIcpThreads = GOICP_ICP_THREADS;     // 4 wavefronts = 16 queries per workgroup
 
 // Upper bound on the NN distance from the distance transform.  For ANY voxel v:
@@ -949,7 +949,7 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 // nn_cache (two float4 per source point: {q_ref.xyz, sqrt(best2_ref)}, {neighbour xyz, its original index}) != nullptr:
 // the exact skip test of rows_nearest<TWO>'s comment; entries never go stale (they are statements about the static
 // target cloud), an entry with sqrt(best2_ref) = 0 (fresh engine, tied neighbours) always walks.
-template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2, bool STRIDED = false>
+template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2, bool STRIDED = false, bool ACC = false>
 __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                   IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                                   float* __restrict__ partials, int* __restrict__ ticket,
@@ -1042,6 +1042,13 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 				__hip_atomic_store(reinterpret_cast<unsigned long long*>(partials + (size_t)blockIdx.x * kIcpAcc + threadIdx.x), pk, __ATOMIC_RELAXED,
 				                   __HIP_MEMORY_SCOPE_AGENT);
 			}
+		} else if constexpr (ACC) {
+			// no row of partial sums per workgroup (on the bunny the finalize spent 4.2 of its 9.4 us fetching and adding
+			// 1 899 of them) but 16 device-scope 64-bit integer adds of the sums in fixed point -- integer addition is
+			// associative, so the totals are exact and independent of the arrival order: still bit-reproducible
+			const long long v = __double2ll_rn((double)sum * (double)st->acc_scale);
+			unsigned long long* a = reinterpret_cast<unsigned long long*>(partials) + (size_t)(blockIdx.x & (kIcpAccReplicas - 1)) * kIcpAcc + threadIdx.x;
+			__hip_atomic_fetch_add(a, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
 			partials[(size_t)blockIdx.x * kIcpAcc + threadIdx.x] = sum;
 		}
@@ -1592,6 +1599,33 @@ __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* 
 	if (threadIdx.x < 64) finalize_rows(sh.sums, state, sh.st, (int)threadIdx.x);
 }
 
+// the finalize of the fixed-point form: 32 replicas x 16 accumulators in, zeroed again on the way out
+__global__ __launch_bounds__(kFinThreads) void icp_finalize_update_acc(unsigned long long* __restrict__ acc, IcpState* __restrict__ state)
+{
+	__shared__ FinScratch sh;
+	__shared__ long long wtot[kIcpAccReplicas * kIcpAcc / 64][kIcpAcc];
+	static_assert(kIcpAccReplicas * kIcpAcc <= kFinThreads && (kIcpAccReplicas * kIcpAcc) % 64 == 0, "one accumulator per thread, whole wavefronts");
+	if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<unsigned*>(&sh.st)[threadIdx.x] = reinterpret_cast<const unsigned*>(state)[threadIdx.x];
+	if (state->converged) return;                 // uniform; the pass kernel added nothing
+	const int t = threadIdx.x;
+	if (t < kIcpAccReplicas * kIcpAcc) {
+		long long x = (long long)acc[t];
+		acc[t] = 0ull;                            // the next pass starts from zero (it cannot start before this kernel has finished)
+		x += __shfl_xor(x, 16, 64);
+		x += __shfl_xor(x, 32, 64);
+		if ((t & 63) < kIcpAcc) wtot[t >> 6][t & 15] = x;
+	}
+	__syncthreads();
+	if (t < kIcpAcc) {
+		long long tot = 0;
+#pragma unroll
+		for (int w = 0; w < kIcpAccReplicas * kIcpAcc / 64; w++) tot += wtot[w][t];
+		sh.sums[t] = (double)tot * (double)sh.st.acc_inv;
+	}
+	__syncthreads();
+	if (t < 64) finalize_rows(sh.sums, state, sh.st, t);
+}
+
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
 __global__ void kabsch_debug_kernel(const float* __restrict__ H, float* __restrict__ R)
 {
@@ -1704,19 +1738,35 @@ int icp_blocks(int N)
 	return (N + per_block - 1) / per_block;
 }
 
+// the fixed-point form (bricked DT, two launches per iteration): `acc` is the accumulator block; strangers per wavefront up to
+// kIcpStridedMaxN points, neighbours above
+template <int K>
+static void launch_pass_acc(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, unsigned long long* acc, float4* nn_cache,
+                            int* hits, hipStream_t stream)
+{
+	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
+	float* a = reinterpret_cast<float*>(acc);
+	const bool strided = N <= kIcpStridedMaxN;
+	if (nn_cache) {
+		if (strided) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, true, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
+		else hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, false, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
+	} else {
+		if (strided) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, false, 4, true, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
+		else hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, false, 4, false, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
+	}
+}
+
 template <int K, bool FUSED>
 static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, int* ticket, float4* nn_cache,
                           int* hits, hipStream_t stream)
 {
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
 	if (nn_cache) {
-		if (!FUSED && dt.layout && N <= kIcpStridedMaxN) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
-		else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 	} else {
 		// four leaves per scan step (S2 845 -> 926 iterations/s, S1 21.9 k -> 23.0 k, bunny 27.0 k -> 27.1 k)
-		if (!FUSED && dt.layout && N <= kIcpStridedMaxN) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, false, 4, true>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
-		else if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
+		if (dt.layout) hipLaunchKernelGGL((icp_pass_kernel<K, 1, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 		else hipLaunchKernelGGL((icp_pass_kernel<K, 0, FUSED, false, FUSED ? 2 : 4>), grid, block, 0, stream, src, N, st, kd, dt, partials, ticket, nn_cache, hits);
 	}
 }
@@ -1747,8 +1797,16 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 
 // ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream)
+                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc)
 {
+	if (!ticket && acc && dt.layout) {
+		// the default form: fixed-point sums, no rows of partial sums
+		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
+		else if (kd.K == 2) launch_pass_acc<2>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
+		else launch_pass_acc<3>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
+		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinThreads), 0, stream, acc, st);
+		return hipGetLastError();
+	}
 	if (ticket) {
 		if (kd.K == 1) launch_pass_k<1, true>(src, N, st, kd, dt, partials, ticket, nn_cache, hits, stream);
 		else if (kd.K == 2) launch_pass_k<2, true>(src, N, st, kd, dt, partials, ticket, nn_cache, hits, stream);

@@ -134,7 +134,11 @@ struct IcpState {
 	int32_t converged, iters, passes;
 	int32_t carry_means;         // 1: the reference's carried means; 0: fresh means (single-step API)
 	int32_t frozen;              // 1: passes only score, the pose is not updated
+	float acc_scale, acc_inv;    // small clouds: the pass adds its sums as 64-bit fixed point, value * acc_scale (a power of two chosen from the
+	                             // clouds' extent so that N terms cannot overflow), into kIcpAccReplicas x 16 accumulators
 };
+constexpr int kIcpAccReplicas = 32;   // workgroup b adds to replica b % 32: ~60 adds per address and pass (a device-scope atomic takes ~12 ns)
+constexpr int kIcpStridedMaxN = 40000;   // up to this many source points: strangers per wavefront + fixed-point sums (device.hip icp_pass_kernel)
 int icp_blocks(int N);           // workgroups per pass
 size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_icp_iteration must hold
 // ticket: a device int that is zero between launches -> ONE fused launch (the last workgroup to arrive runs the
@@ -142,8 +146,10 @@ size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_i
 // nn_cache: 2 float4 per source point, zero-initialised once (never invalidated: its entries are statements about the
 // static target cloud) -> a pass skips, exactly, the tree walk of every query whose cached neighbour is provably still the
 // nearest; nullptr -> every query walks.
+// acc: kIcpAccReplicas x 16 zeroed 64-bit words (kept zero between iterations by the finalize) -> clouds of up to kIcpStridedMaxN
+// points sum there instead of writing a row of partial sums per workgroup; nullptr -> rows for every size
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream);
+                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,

@@ -408,6 +408,10 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		HIPCHK(hipMalloc(&d_include_, N_));
 	}
 	HIPCHK(hipMalloc(&d_icp_state_, sizeof(IcpState)));
+	HIPCHK(hipMalloc(&d_icp_acc_, sizeof(unsigned long long) * kIcpAccReplicas * kIcpAcc));
+	HIPCHK(hipMemsetAsync(d_icp_acc_, 0, sizeof(unsigned long long) * kIcpAccReplicas * kIcpAcc, stream_));
+	for (size_t i = 0; i < N_; i++) src_radius_ = std::max(src_radius_, h_src_sorted_[4 * i + 3]);
+	for (size_t i = 0; i < 3 * M_; i++) target_abs_max_ = std::max(target_abs_max_, std::fabs(target[i]));
 	if (p_.icp_nn_cache) {
 		HIPCHK(hipMalloc(&d_nn_cache_, sizeof(float4) * 2 * N_));
 		HIPCHK(hipMemsetAsync(d_nn_cache_, 0, sizeof(float4) * 2 * N_, stream_));      // sqrt(best2_ref) = 0: the first pass walks
@@ -491,6 +495,7 @@ void Engine::release()
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
+	hipFree(d_icp_acc_); d_icp_acc_ = nullptr;
 	hipFree(d_icp_partials_); hipFree(d_icp_state_); hipHostFree(h_icp_state_); hipFree(d_icp_ticket_); d_icp_ticket_ = nullptr; hipFree(d_nn_cache_); d_nn_cache_ = nullptr;
 	hipFree(d_nn_d2_); hipFree(d_nn_slot_); hipFree(d_include_);
 	for (Stage& st : stage_) {
@@ -710,6 +715,17 @@ void Engine::icp_state_init(const float R[9], const float t[3], float err_diff, 
 	st.n = (float)inliers_;                        // means over the num correspondences used (the reference divides by n, App. B-12)
 	st.carry_means = carry_means;
 	st.frozen = frozen;
+	{
+		// fixed-point scale of the small-cloud pass: every term is a coordinate difference, a product of two, or a squared
+		// distance between a moved source point and the target, all below L^2 with L the sum of the extents; N of them must
+		// fit 2^62.  ICP moves the cloud towards the target, so the start pose bounds the run.
+		const double tl = std::sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+		const double L = 2.0 * ((double)src_radius_ + tl + std::sqrt(3.0) * (double)target_abs_max_ + 1.0);
+		int e = (int)std::floor(std::log2(4.6e18 / ((double)std::max<size_t>(N_, 1) * L * L)));
+		e = std::max(-60, std::min(60, e));
+		st.acc_scale = std::ldexp(1.0f, e);
+		st.acc_inv = std::ldexp(1.0f, -e);
+	}
 	HIPCHK(hipMemcpyAsync(d_icp_state_, h_icp_state_, sizeof(IcpState), hipMemcpyHostToDevice, stream_));
 }
 
@@ -719,7 +735,7 @@ void Engine::icp_launch_one()
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
 		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
-		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_));
+		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
 }
 
 void Engine::icp_state_fetch()

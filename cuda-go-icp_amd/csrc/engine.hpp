@@ -231,6 +231,8 @@ private:
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;
+	unsigned long long* d_icp_acc_ = nullptr;   // fixed-point sums of the small-cloud ICP pass (kIcpAccReplicas x 16, zero between iterations)
+	float src_radius_ = 0.f, target_abs_max_ = 0.f;   // extents that bound the pass's terms (IcpState::acc_scale)
 	float4* d_nn_cache_ = nullptr;     // per source point: {q_ref, sqrt(best2_ref)}, {neighbour, index} (exact walk-skipping, device.hip)
 	bool count_hits_ = false;
 	int* d_icp_ticket_ = nullptr;      // arrival ticket of the fused ICP iteration (zero between launches)

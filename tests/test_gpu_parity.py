@@ -294,6 +294,38 @@ def test_icp_first_pass_error_is_bruteforce_nn_sum(pkg, oracle_mod, bunny_model,
     reg.close()
 
 
+def test_icp_fixed_point_sums_scale_and_repeat(pkg, bunny_model, bunny_data10):
+    """The pass adds its workgroup sums as 64-bit fixed point (integer atomics; the scale is derived from the clouds'
+    extents and the start pose).  (1) The same clouds in other units -- x500 and pushed 300 units off the origin, and
+    x1e-3 -- take the same ICP trajectory: same iteration count, same rotation, translation scaled, error scaled by the
+    square (no overflow, no loss of resolution).  (2) Integer sums do not depend on the order the workgroups arrive in:
+    two runs of the same ICP give bit-identical poses.  (3) A start pose far outside the clouds is still summed right
+    (the scale follows the start pose): first-pass error against brute force."""
+    base = pkg.Registration(bunny_model, bunny_data10, 1e-3)
+    icp0 = pkg.IterativeClosestPoint3D(base, 40, 1e-7, np.eye(3), np.zeros(3))
+    e0, R0, t0 = icp0.run()
+    icp1 = pkg.IterativeClosestPoint3D(base, 40, 1e-7, np.eye(3), np.zeros(3))
+    e1, R1, t1 = icp1.run()
+    assert e0 == e1 and np.array_equal(R0, R1) and np.array_equal(t0, t1) and icp0.iters == icp1.iters
+    for s, off in ((500.0, np.array([300.0, -120.0, 40.0], np.float32)), (1e-3, np.zeros(3, np.float32))):
+        reg = pkg.Registration((bunny_model * np.float32(s) + off).astype(np.float32), (bunny_data10 * np.float32(s) + off).astype(np.float32), 1e-3)
+        icp = pkg.IterativeClosestPoint3D(reg, 40, 1e-7 * s * s, np.eye(3), np.zeros(3))
+        e, R, t = icp.run()
+        # x' = s x + off on both clouds: R' = R, t' = s t + off - R off
+        assert np.abs(R - R0).max() <= 2e-3, (s, np.abs(R - R0).max())
+        assert np.abs(t - (s * t0 + off - R0 @ off)).max() <= 5e-3 * s * max(1.0, np.abs(off).max() / s / 10), (s, t, t0)
+        assert abs(e - e0 * s * s) <= 2e-2 * e0 * s * s, (s, e, e0)
+        reg.close()
+    far = np.array([40.0, -25.0, 10.0], np.float32)
+    one = pkg.IterativeClosestPoint3D(base, 1, 1e-7, np.eye(3), far)
+    err_far, _, _ = one.run()
+    q = (bunny_data10 + far).astype(np.float32)
+    from scipy.spatial import cKDTree
+    dd, _ = cKDTree(bunny_model.astype(np.float64)).query(q.astype(np.float64))
+    assert abs(err_far - float((dd ** 2).sum())) <= 1e-4 * float((dd ** 2).sum())
+    base.close()
+
+
 def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):
     reg = pkg.Registration(bunny_model, bunny_data10, 1e-3)
     errs = [reg.icp_step().best_sse for _ in range(6)]

@@ -418,7 +418,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	}
 	HIPCHK(hipMalloc(&d_icp_ticket_, 64));
 	HIPCHK(hipMemset(d_icp_ticket_, 0, 64));
-	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState)));
+	HIPCHK(hipHostMalloc(&h_icp_state_, sizeof(IcpState) * 3));      // [0] the state as uploaded / as last fetched, [1], [2] icp_run's two fetch slots
 	ensure_batch(4096, 64);
 	if (p_.device_queues && p_.trans_batch > 1 && p_.wide_children) {
 		// the device-resident inner-BnB queues, sized for a full round of the outer search, and their pinned mirror touched
@@ -748,16 +748,34 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 {
 	DeviceGuard guard(dev_);
 	icp_state_init(R, t, err_diff, 1, 0);
+	// Chunks of iterations, one chunk ahead: while the host waits for and looks at the state after chunk k, chunk k+1 is
+	// already queued, so the GPU never idles between chunks (a blocking fetch per chunk cost ~4 us per iteration on the
+	// bunny).  Once the state has converged the queued launches are no-ops (every kernel tests the flag first).
 	const int chunk = std::max(1, p_.icp_chunk);
 	int queued = 0;
-	while (queued < max_iter) {
+	IcpState* slots = h_icp_state_ + 1;
+	hipEvent_t evs[2] = {ev0_, ev1_};
+	auto submit = [&](int slot) -> bool {
+		if (queued >= max_iter) return false;
 		const int k = std::min(chunk, max_iter - queued);
 		for (int i = 0; i < k; i++) icp_launch_one();
 		queued += k;
-		icp_state_fetch();
-		if (h_icp_state_->converged || cancel_.load()) break;
+		HIPCHK(hipMemcpyAsync(&slots[slot], d_icp_state_, sizeof(IcpState), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipEventRecord(evs[slot], stream_));
+		return true;
+	};
+	int cur = 0;
+	bool have = submit(0);
+	const IcpState* fin = nullptr;
+	while (have) {
+		const bool next = submit(cur ^ 1);
+		HIPCHK(hipEventSynchronize(evs[cur]));
+		fin = &slots[cur];
+		if (fin->converged || cancel_.load()) break;
+		have = next;
+		cur ^= 1;
 	}
-	if (max_iter <= 0) icp_state_fetch();
+	if (fin) *h_icp_state_ = *fin; else icp_state_fetch();      // max_iter <= 0: the state as uploaded
 	const IcpState& st = *h_icp_state_;
 	std::memcpy(R, st.R, sizeof(st.R));
 	std::memcpy(t, st.t, sizeof(st.t));

@@ -360,7 +360,8 @@ __host__ __device__ inline void bounds_shape(int B, int N, int* groups, int* chu
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots, const ParentRec* __restrict__ parents,
-    const int* __restrict__ d_groups, int* __restrict__ work8, float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
+    const int* __restrict__ d_groups, int* __restrict__ work8, int* __restrict__ d_chunks, float* __restrict__ scratch, float* __restrict__ ub_out,
+    float* __restrict__ lb_out)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
 	__shared__ int next_item[2];
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	if (ngroups <= 0) return;
 	int groups, chunks, chunk_pts;
 	bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
+	if (blockIdx.x == 0 && threadIdx.x == 0) *d_chunks = chunks;          // > 1: the next round's digest adds the chunk partials up
 	const int total = groups * chunks;
 	const bool per_xcd = (total & 7) == 0;
 	const int slot = per_xcd ? (int)(blockIdx.x & 7) : 0, stride = per_xcd ? 8 : 1;
@@ -382,23 +384,6 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 		__syncthreads();                                                 // `red` is reused by the next item; next_item is published
 		buf ^= 1;
 		item = next_item[buf];
-	}
-}
-
-__global__ void bounds_queue_finalize(const float* __restrict__ scratch, const int* __restrict__ d_groups, int N,
-                                      float* __restrict__ ub_out, float* __restrict__ lb_out)
-{
-	const int ngroups = *d_groups;
-	if (ngroups <= 0) return;
-	int groups, chunks, chunk_pts;
-	bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
-	if (chunks == 1) return;                                             // written directly by the evaluation kernel
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < groups * 2 * kGroup; t += gridDim.x * blockDim.x) {
-		const int group = t / (2 * kGroup), k = t - group * 2 * kGroup;
-		const float* s = scratch + (size_t)group * chunks * (2 * kGroup) + k;
-		float acc = 0.f;
-		for (int j = 0; j < chunks; j++) acc += s[(size_t)j * 2 * kGroup];
-		(k < kGroup ? ub_out : lb_out)[group * kGroup + (k & (kGroup - 1))] = acc;
 	}
 }
 
@@ -431,9 +416,10 @@ template <int LAYOUT>
 __global__ __launch_bounds__(kTrimThreads) void bounds_trim_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int inliers,
-    float* __restrict__ ub_out, float* __restrict__ lb_out, const int* __restrict__ d_groups)
+    float* __restrict__ ub_out, float* __restrict__ lb_out, const int* __restrict__ d_groups, int* __restrict__ d_chunks = nullptr)
 {
 	if (d_groups) {                           // batch size known to the device only (device-resident BnB queues)
+		if (d_chunks && blockIdx.x == 0 && threadIdx.x == 0) *d_chunks = 1;     // this form writes the final bounds itself
 		if ((int)blockIdx.x >= *d_groups) return;
 		B = *d_groups * kGroup;
 	}
@@ -557,8 +543,8 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 	if (B <= 0 || N <= 0) return hipSuccess;
 	const dim3 grid((B + kGroup - 1) / kGroup), block(kTrimThreads);
 	if (dt.layout == 2) return hipErrorInvalidValue;          // the trimmed form is evaluated on the fp32 grid
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
-	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr, (int*)nullptr);
+	else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, inliers, ub, lb, (const int*)nullptr, (int*)nullptr);
 	return hipGetLastError();
 }
 
@@ -596,22 +582,21 @@ size_t bounds_queue_scratch_floats(int max_groups)
 }
 
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
-                               int* d_work8, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream)
+                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream)
 {
 	if (max_groups <= 0 || N <= 0) return hipSuccess;
 	if (inliers < N) {
 		// trimmed form: one workgroup per expansion, the surplus workgroups of the fixed grid leave at once
 		const dim3 grid(max_groups), block(kTrimThreads);
 		if (dt.layout == 2) return hipErrorInvalidValue;
-		if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
-		else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups);
+		if (dt.layout == 0) hipLaunchKernelGGL(bounds_trim_kernel<0>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups, d_chunks);
+		else hipLaunchKernelGGL(bounds_trim_kernel<1>, grid, block, 0, stream, src, N, dt, rots, (const CubeRec*)nullptr, parents, 0, inliers, ub, lb, d_groups, d_chunks);
 		return hipGetLastError();
 	}
 	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
-	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
-	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, scratch, ub, lb);
-	hipLaunchKernelGGL(bounds_queue_finalize, dim3(256), dim3(256), 0, stream, scratch, d_groups, N, ub, lb);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
+	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
+	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
 	return hipGetLastError();
 }
 

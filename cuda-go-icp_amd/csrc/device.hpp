@@ -96,7 +96,9 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 };
 struct QCtl {
 	int32_t n_groups[2];            // expansions listed per round parity
-	int32_t overflow, pad;
+	int32_t overflow;
+	int32_t chunks;                 // point chunks per expansion of the last bound evaluation: > 1 -> its sums are chunk partials in the scratch block,
+	                                // added up by the next round's digest (bnb_queue_kernel) -- no separate finalize launch
 	int32_t work[2][8];             // per round parity and XCD slot: next work item of the bound evaluation (dynamic distribution)
 };
 struct QParams {
@@ -112,10 +114,11 @@ struct QInit { int32_t slot; float best; float coeff; int32_t rot; };
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream);
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, QCtl* ctl, int parity, hipStream_t stream);
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream);
 // bounds of the 8 children of the *d_groups expansions in `parents` (count known to the device only); max_groups sizes the grids
+// (d_chunks: QCtl::chunks -- the evaluation leaves chunk partials in `scratch` when it splits the cloud, and says so there)
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
-                               int* d_work8, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream);
+                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream);
 size_t bounds_queue_scratch_floats(int max_groups);
 
 // ---- ICP ------------------------------------------------------------------------------------

@@ -455,8 +455,8 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * kFlowSearches, hipMemcpyHostToDevice, stream_));
 			HIPCHK(launch_bnb_init_list(d_qsearch_, d_qnodes_, d_qinit_, 1, qp, stream_));
 			for (int r = 0; r < 3; r++) {
-				HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, kFlowSearches, qp, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qctl_, q_parity_, stream_));
-				HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0],
+				HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, kFlowSearches, qp, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));
+				HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0], &d_qctl_->chunks,
 				                           kFlowSearches * qp.K, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
 				q_parity_ ^= 1;
 			}
@@ -950,8 +950,8 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		int last = 0;
 		const int max_groups = (int)(S * (size_t)qp.K);
 		for (int r = 0; r < chunk; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qctl_, parity, stream_));
-			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], max_groups,
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
 			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
 			last = parity;
 			parity ^= 1;
@@ -1439,8 +1439,8 @@ int Engine::flow_step(int max_rot_pops)
 		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueMaxPop : (flow_active_ <= 64 ? std::min(kQueueMaxPop, 2 * qp.K) : qp.K);
 		const int max_groups = q_hi_ * qr.K;
 		for (int r = 0; r < 3; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qctl_, q_parity_, stream_));
-			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0],
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0], &d_qctl_->chunks,
 			                           max_groups, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
 			q_parity_ ^= 1;
 			cnt_.bounds_launches++;

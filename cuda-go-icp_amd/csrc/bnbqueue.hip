@@ -46,6 +46,7 @@ struct QShared {
 	unsigned push_tot[kQThreads / 64];
 	int n_sel, n_holes, parent_off, bcast;
 	int hole_cnt[2], fill_cnt[2];
+	float psum[2 * kQThreads];                     // digest: partial sums of the chunk partials, [child][part] for ub, then for lb
 };
 
 __device__ __forceinline__ int node_depth(float root_w, float w)      // w = root_w * 2^-depth exactly
@@ -88,6 +89,22 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	if (n_prev > 0) {
 		const int C = 8 * n_prev, off = S->parent_off;
 		const bool mine = tid < C;
+		// The evaluation split the cloud into `chunks` chunks: its per-chunk sums are added here (this replaces a finalize launch
+		// per round).  Small rounds have few children and many chunks (up to 118), so the sum is spread over the workgroup: P
+		// threads per child add every P-th chunk partial, the child's own thread adds the P results in order.  Fixed order
+		// for given (children, chunks): deterministic.
+		const int chunks = ctl->chunks;
+		const int P = chunks > 1 ? max(1, min(chunks, kQThreads / C)) : 1;
+		if (chunks > 1) {
+			if (tid < C * P) {
+				const int c = tid / P, p = tid - c * P;
+				const float* sp = scratch + ((size_t)(off + (c >> 3)) * chunks) * (2 * kGroup) + (c & 7);
+				float a = 0.f, b = 0.f;
+				for (int j = p; j < chunks; j += P) { a += sp[(size_t)j * 2 * kGroup]; b += sp[(size_t)j * 2 * kGroup + kGroup]; }
+				sh.psum[tid] = a; sh.psum[kQThreads + tid] = b;
+			}
+			__syncthreads();
+		}
 		float cx = 0.f, cy = 0.f, cz = 0.f, cw = 0.f, ub = INFINITY, lb = INFINITY;
 		bool valid = false;
 		if (mine) {
@@ -95,13 +112,9 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			const int c = tid & 7;
 			cw = pr.w / 2;                                            // jly_goicp.cpp:262-270
 			cx = pr.x + (float)(c & 1) * cw; cy = pr.y + (float)((c >> 1) & 1) * cw; cz = pr.z + (float)((c >> 2) & 1) * cw;
-			const int chunks = ctl->chunks;
 			if (chunks > 1) {
-				// the evaluation split the cloud into chunks: its per-chunk sums are added here, in chunk order (the order and
-				// the float arithmetic of the finalize launch this replaces -- 6 us per round, bit-identical bounds)
-				const float* sp = scratch + ((size_t)(off + (tid >> 3)) * chunks) * (2 * kGroup) + c;
 				float a = 0.f, b = 0.f;
-				for (int j = 0; j < chunks; j++) { a += sp[(size_t)j * 2 * kGroup]; b += sp[(size_t)j * 2 * kGroup + kGroup]; }
+				for (int p = 0; p < P; p++) { a += sh.psum[tid * P + p]; b += sh.psum[kQThreads + tid * P + p]; }
 				ub = a; lb = b;
 			} else {
 				ub = ubs[(size_t)8 * off + tid]; lb = lbs[(size_t)8 * off + tid];

@@ -556,13 +556,16 @@ __host__ __device__ inline void bounds_shape(int B, int N, int* groups, int* chu
 	const int target_blocks = 1024;   // measured on the BnB's small batches: 512..2048 within 5 %, larger is slower
 	const int max_chunks = (N + kBoundsThreads - 1) / kBoundsThreads;
 	int c = (target_blocks + g - 1) / g;
-	if (max_chunks >= 8) c = (c + 7) / 8 * 8;
-	if (c > max_chunks) c = max_chunks >= 8 ? max_chunks / 8 * 8 : max_chunks;
+	// eight chunk sets only when each of them still gets >= 4 iterations of 256 points: a workgroup's fixed cost (cube records,
+	// reduction, partial row) is spread over too few points otherwise (bunny/10, N = 3 038: 8 chunks of 380 points)
+	const bool sets = max_chunks >= 32;
+	if (sets) c = (c + 7) / 8 * 8;
+	if (c > max_chunks) c = sets ? max_chunks / 8 * 8 : max_chunks;
 	if (c < 1) c = 1;
 	int cp = (N + c - 1) / c;
 	cp = (cp + kBoundsThreads - 1) / kBoundsThreads * kBoundsThreads;
 	int c2 = (N + cp - 1) / cp;                 // rounding the chunk size up may empty the last chunks
-	if ((c & 7) == 0 && c2 != c) { /* keep c: trailing chunks are simply empty */ } else c = c2;
+	if (sets && (c & 7) == 0 && c2 != c) { /* keep c: trailing chunks are simply empty */ } else c = c2;
 	*groups = g; *chunks = c; *chunk_pts = cp;
 }
 

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Soak run (manual, GPU box): engines created, run and destroyed in a loop; every registration of the same input must
+return the same bits (SSE, R, t), and the free device memory after the last engine must equal the free memory after the
+first one (no leak).  usage: python tools/soak.py [rounds]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import _pkg  # noqa: E402
+
+pkg = _pkg()
+pkg.load_library()
+hip = C.CDLL("libamdhip64.so")
+
+
+def free_mem():
+    f, t = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+    return f.value
+
+
+g = os.path.join(ROOT, "tests", "golden")
+cloud = lambda n, s=1: np.fromfile(os.path.join(g, n + ".f32"), dtype="<f4").reshape(-1, 3)[::s]
+cases = {"bunny10": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {}),
+         "rand100": (cloud("model_rand"), cloud("data_rand"), 1e-3, {}),
+         "bunny10_trim": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"trim_fraction": 0.1}),
+         "bunny10_flow": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"flow": 8})}
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+ref, base = {}, None
+t0 = time.time()
+for r in range(rounds):
+    for name, (tg, sr, mse, kw) in cases.items():
+        eng = pkg.FastGoICP(tg, sr, mse, **kw)
+        eng.run()
+        sig = (eng.get_best_error(), eng.optR.tobytes(), eng.optT.tobytes(), int(eng.counters.cubes))
+        eng.run()                                   # the same engine again
+        sig2 = (eng.get_best_error(), eng.optR.tobytes(), eng.optT.tobytes(), int(eng.counters.cubes))
+        eng.registration.close()
+        assert sig == sig2, (name, "second run of one engine differs")
+        if name in ref:
+            assert ref[name] == sig, (name, r, "run differs from the first engine's", sig[0], ref[name][0])
+        ref[name] = sig
+    fm = free_mem()
+    if r == 0:
+        base = fm
+    if r % 10 == 9 or r == rounds - 1:
+        print("round %d: %.1f s, free device memory %+d KiB vs after the first round" % (r + 1, time.time() - t0, (fm - base) // 1024), flush=True)
+assert abs(free_mem() - base) <= (64 << 20), "device memory drifted"
+print("soak ok: %d rounds x %d cases, bit-identical results, no memory drift" % (rounds, len(cases)))

@@ -46,6 +46,7 @@ struct QShared {
 	unsigned push_tot[kQThreads / 64];
 	int n_sel, n_holes, parent_off, bcast;
 	int hole_cnt[2], fill_cnt[2];
+	unsigned char tail_sel[kQueueMaxPop];          // removal: is tail position m + t one of the selected nodes?
 	float psum[2 * kQThreads];                     // digest: partial sums of the chunk partials, [child][part] for ub, then for lb
 };
 
@@ -344,11 +345,16 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	// unselected nodes of the tail [m, n)  (at most n_sel <= 128 of each: the first two wavefronts do it)
 	const int m = n - n_sel;
 	{
+		// which of the (at most n_sel) tail positions [m, n) are themselves selected: their owners say so
+#pragma unroll
+		for (int j = 0; j < kQPer; j++) {
+			const int i = j * kQThreads + tid;
+			if (i >= m && i < n) sh.tail_sel[i - m] = sel[j] ? 1 : 0;
+		}
+		__syncthreads();
 		const bool is_hole = tid < n_sel && sh.sel_pos[tid < kQueueMaxPop ? tid : 0] < m;
 		const int tailpos = m + tid;
-		bool filler = tid < n_sel && tailpos < n;
-		if (filler)
-			for (int r = 0; r < n_sel; r++) if (sh.sel_pos[r] == tailpos) filler = false;
+		const bool filler = tid < n_sel && tailpos < n && !sh.tail_sel[tid < kQueueMaxPop ? tid : 0];
 		const unsigned long long hb = __ballot(is_hole), fb = __ballot(filler);
 		if (wave < 2 && lane == 0) { sh.hole_cnt[wave] = (int)__popcll(hb); sh.fill_cnt[wave] = (int)__popcll(fb); }
 		__syncthreads();

@@ -150,7 +150,51 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 #pragma unroll
 		for (int w2 = 0; w2 < kQThreads / 64; w2++) { if (w2 < wave) before += sh.push_tot[w2]; total += sh.push_tot[w2]; }
 		if (count + (int)total > qp.cap) {
-			// does not fit: flag it; the host re-runs the whole batch through its own queues (nothing is lost)
+			// The slab is full.  First throw out what can never be expanded: a queued node whose lower bound has come within
+			// SSEThresh of the incumbent since it was pushed fails the stop rule (jly_goicp.cpp:257) whenever it is popped --
+			// in a long upper-bound search the incumbent keeps falling and most of the queue is such dead weight.  Survivors
+			// keep their order.  (The reference's heap just grows; the slab cannot.)
+			QNode nd[kQPer];
+			bool keep[kQPer];
+#pragma unroll
+			for (int j = 0; j < kQPer; j++) {
+				const int i = j * kQThreads + tid;
+				keep[j] = false;
+				if (i < count) { nd[j] = Q[i]; keep[j] = !(best - nd[j].lb < qp.thr); }
+			}
+#pragma unroll
+			for (int j = 0; j < kQPer; j++) {
+				const unsigned long long kb = __ballot(keep[j]);
+				if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(kb);
+			}
+			__syncthreads();                                              // every node is in registers; the counts are in LDS
+			{
+				unsigned wbefore = 0, tot = 0;
+				if (lane < kQPer)
+					for (int w2 = 0; w2 < kQThreads / 64; w2++) {
+						const unsigned c = sh.cnt[lane][w2];
+						tot += c;
+						wbefore += w2 < wave ? c : 0u;
+					}
+				unsigned incl = tot;
+#pragma unroll
+				for (int o = 1; o < kQPer; o <<= 1) {
+					const unsigned v = __shfl_up(incl, o, 64);
+					if (lane >= o) incl += v;
+				}
+				const unsigned base = incl - tot + wbefore;               // lane j: survivors before (slot j, this wavefront)
+				if (tid == kQPer - 1) sh.bcast = (int)incl;               // wavefront 0: the number of survivors
+#pragma unroll
+				for (int j = 0; j < kQPer; j++) {
+					const unsigned long long kb = __ballot(keep[j]);
+					if (keep[j]) Q[(unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(kb & ((1ull << lane) - 1ull))] = nd[j];
+				}
+			}
+			__syncthreads();
+			count = sh.bcast;
+		}
+		if (count + (int)total > qp.cap) {
+			// still does not fit: flag it; the host re-runs the whole batch through its own queues (nothing is lost)
 			if (tid == 0) { atomicExch(&ctl->overflow, 1); S->done = 1; S->n_parents = 0; }
 			return;
 		}

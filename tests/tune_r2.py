@@ -59,7 +59,7 @@ elif which == "flowsweep":
                 t1 = time.time(); eng.run(); dt = time.time() - t1; c = eng.counters
                 best = min(best, dt) if best else dt
                 sse = eng.get_best_error(); eng.registration.close()
-            print("%-9s flow=%-3d ak=%d best %.4fs sse %.4f rot_pops %d cubes %d rounds %d icp %d" % (name, fl, ak, best, sse, c.rot_pops, c.cubes, c.bounds_launches, c.icp_iters), flush=True)
+            print("%-9s flow=%-3d ak=%d best %.4fs sse %.4f rot_pops %d cubes %d rounds %d icp %d fallbacks %d" % (name, fl, ak, best, sse, c.rot_pops, c.cubes, c.bounds_launches, c.icp_iters, c.queue_fallbacks), flush=True)
 elif which == "flow":
     for fl in (1, 0, 1, 0):
         for K in (32, 16):

@@ -1,7 +1,9 @@
-"""Exploration on the GPU box (not a test): spanner and S2 registrations at several thresholds."""
+"""Exploration on the GPU box (not a test): registrations of the test workloads under the driver options
+(`flowsweep`: lock-step / continuous flow x round width on six workloads -- the tables of DESIGN section 4 --, `spanner`, `s2`,
+`bunny`, `ksweep`, `ramp`, `flow`, `create`).  usage: python3 tools/tune_r2.py <mode>"""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_pkg, cloud, rot_angle
 pkg = load_pkg(); pkg.load_library()
 which = sys.argv[1] if len(sys.argv) > 1 else "spanner"

@@ -540,7 +540,15 @@ def main():
 
     if rank == 0:
         out["e2e_sharded"] = sharded_res
-        print(json.dumps(out), flush=True)
+        def _clean(o):                      # NaN (a leg that was switched off) is not JSON: null instead
+            if isinstance(o, float) and o != o:
+                return None
+            if isinstance(o, dict):
+                return {k: _clean(v) for k, v in o.items()}
+            if isinstance(o, list):
+                return [_clean(v) for v in o]
+            return o
+        print(json.dumps(_clean(out), allow_nan=False), flush=True)
     if sharded_hung:
         # a rank is still inside a collective that will never complete: the line is out, leave without the teardown
         sys.stdout.flush()

@@ -1283,77 +1283,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accum_kernel(const float4* __
 	}
 }
 
-// ---- 3x3 SVD (one-sided Jacobi, double) -> Kabsch rotation, on the device ---------------------------
-__device__ void kabsch_rotation_dev(const double H[9], float R[9])
-{
-	double B[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, U[9], W[3];
-	for (int i = 0; i < 9; i++) B[i] = H[i];
-	for (int sweep = 0; sweep < 32; sweep++) {
-		bool rotated = false;
-		for (int p = 0; p < 2; p++)
-			for (int q = p + 1; q < 3; q++) {
-				double app = 0, aqq = 0, apq = 0;
-				for (int i = 0; i < 3; i++) {
-					app += B[3 * i + p] * B[3 * i + p];
-					aqq += B[3 * i + q] * B[3 * i + q];
-					apq += B[3 * i + p] * B[3 * i + q];
-				}
-				// columns orthogonal to 1e-12 relative: the rotation is returned in float (6e-8)
-				if (apq == 0.0 || apq * apq <= 1e-24 * (app * aqq)) continue;
-				rotated = true;
-				// tan(theta) = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq - app) / (2 apq), written
-				// with one square root, one division and one reciprocal square root: this lane is the
-				// serial tail of every ICP iteration and fp64 div / sqrt are ~200-cycle sequences
-				const double da = aqq - app, db = 2 * apq;
-				const double tn = (da >= 0 ? db : -db) / (fabs(da) + sqrt(da * da + db * db));
-				const double cs = rsqrt(1 + tn * tn), sn = cs * tn;
-				for (int i = 0; i < 3; i++) {
-					const double bp = B[3 * i + p], bq = B[3 * i + q];
-					B[3 * i + p] = cs * bp - sn * bq;
-					B[3 * i + q] = sn * bp + cs * bq;
-					const double vp = V[3 * i + p], vq = V[3 * i + q];
-					V[3 * i + p] = cs * vp - sn * vq;
-					V[3 * i + q] = sn * vp + cs * vq;
-				}
-			}
-		if (!rotated) break;
-	}
-	for (int j = 0; j < 3; j++) {
-		const double n2 = B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j];
-		const double rn = n2 > 0 ? rsqrt(n2) : 0.0;
-		W[j] = n2 * rn;
-		for (int i = 0; i < 3; i++) U[3 * i + j] = B[3 * i + j] * rn;
-	}
-	for (int j = 0; j < 3; j++) {          // rank-2 input: complete the missing left vector
-		if (W[j] > 1e-200) continue;
-		const int a = (j + 1) % 3, b = (j + 2) % 3;
-		if (W[a] <= 1e-200 || W[b] <= 1e-200) continue;
-		U[j] = U[3 + a] * U[6 + b] - U[6 + a] * U[3 + b];
-		U[3 + j] = U[6 + a] * U[b] - U[a] * U[6 + b];
-		U[6 + j] = U[a] * U[3 + b] - U[3 + a] * U[b];
-	}
-	double VUt[9];
-	for (int i = 0; i < 3; i++)
-		for (int j = 0; j < 3; j++) {
-			double s = 0;
-			for (int k = 0; k < 3; k++) s += V[3 * i + k] * U[3 * j + k];
-			VUt[3 * i + j] = s;
-		}
-	const double det = VUt[0] * (VUt[4] * VUt[8] - VUt[5] * VUt[7]) - VUt[1] * (VUt[3] * VUt[8] - VUt[5] * VUt[6]) +
-	                   VUt[2] * (VUt[3] * VUt[7] - VUt[4] * VUt[6]);
-	// the reference sorts singular values in decreasing order (matrix.cpp:782-808): its diag(1,1,det)
-	// (jly_icp3d.hpp:268-285) corrects the direction of the smallest one
-	int ks = 0;
-	if (W[1] < W[ks]) ks = 1;
-	if (W[2] < W[ks]) ks = 2;
-	for (int i = 0; i < 3; i++)
-		for (int j = 0; j < 3; j++) {
-			double s = 0;
-			for (int k = 0; k < 3; k++) s += V[3 * i + k] * (k == ks ? det : 1.0) * U[3 * j + k];
-			R[3 * i + j] = (float)s;
-		}
-}
-
 // Sum the per-block partials in double (fixed order -> deterministic), then -- one lane -- the body of
 // the ICP loop after the correspondence pass (jly_icp3d.hpp:253-292): convergence test, means, H,
 // SVD, R_ / t_, compose.  The pose lives in device memory, so the host can queue several iterations
@@ -1424,7 +1353,8 @@ __device__ __forceinline__ double lane_const(double x)
 }
 __device__ __forceinline__ double sum3(double x) { return (lane_const<0>(x) + lane_const<1>(x)) + lane_const<2>(x); }
 
-// rows of H in (b0, b1, b2) on lanes 0..2 -> row of the Kabsch rotation in r[3] (same algorithm as kabsch_rotation_dev)
+// rows of H in (b0, b1, b2) on lanes 0..2 -> row of the Kabsch rotation in r[3]: 3x3 SVD by one-sided Jacobi sweeps in double,
+// R = V diag(1,1,det) U^T with the sign on the smallest singular direction (jly_icp3d.hpp:268-285, matrix.cpp:782-808)
 __device__ __forceinline__ void kabsch_rows(double b0, double b1, double b2, int row, float r[3])
 {
 	double v0 = row == 0 ? 1.0 : 0.0, v1 = row == 1 ? 1.0 : 0.0, v2 = row == 2 ? 1.0 : 0.0;
@@ -1617,12 +1547,12 @@ __global__ __launch_bounds__(kFinThreads) void icp_finalize_update_acc(unsigned 
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
 __global__ void kabsch_debug_kernel(const float* __restrict__ H, float* __restrict__ R)
 {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	double Hd[9];
-	float Rf[9];
-	for (int i = 0; i < 9; i++) Hd[i] = (double)H[i];
-	kabsch_rotation_dev(Hd, Rf);
-	for (int i = 0; i < 9; i++) R[i] = Rf[i];
+	// the production routine: lane i < 3 holds row i of H, gets row i of R (the other lanes shadow lane 2)
+	if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+	const int a = threadIdx.x < 3 ? (int)threadIdx.x : 2;
+	float Rrow[3];
+	kabsch_rows((double)H[3 * a], (double)H[3 * a + 1], (double)H[3 * a + 2], a, Rrow);
+	if (threadIdx.x < 3) { R[3 * a] = Rrow[0]; R[3 * a + 1] = Rrow[1]; R[3 * a + 2] = Rrow[2]; }
 }
 hipError_t launch_kabsch_debug(const float* d_H, float* d_R, hipStream_t stream)
 {

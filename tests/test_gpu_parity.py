@@ -762,7 +762,7 @@ def test_dt_lookup_point_by_point(pkg, oracle_dt_bunny, bunny_model):
 
 
 def test_device_svd_golden(pkg):
-    """SURVEY a-6: the device-side Kabsch / SVD routine (one-sided Jacobi in fp64, device.hip kabsch_rotation_dev)
+    """SURVEY a-6: the device-side Kabsch / SVD routine (one-sided Jacobi in fp64, device.hip kabsch_rows: the routine the ICP finalize runs, three lanes wide)
     fed the reference's own Matrix::svd cases (tests/golden/svd3x3.json: 32 H, half of them x1000 scale),
     R_ = V diag(1,1,det(V U^T)) U^T as jly_icp3d.hpp:266-285.  1e-5 as SURVEY 8c-6."""
     import ctypes as C

@@ -999,6 +999,24 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
         r.close()
 
 
+def test_queue_purges_dead_nodes_before_overflow(pkg):
+    """A long upper-bound search (synthetic S1 pair at mse 1e-4: one rotation child's translation search runs ~4 700
+    expansions while its incumbent keeps falling) pushes more than the 8 192 nodes its slab holds; most of them are dead
+    by then -- their lower bound has come within SSEThresh of the incumbent, so the stop rule (jly_goicp.cpp:257) rejects
+    them whenever they are popped.  The queue kernel throws those out instead of flagging the batch: no host fallback, and
+    the registration is the host-queue driver's (which has no cap) to the same optimum."""
+    from cuda_go_icp_amd import synth
+    tg, sr, Rgt, tgt = synth.make_pair(**{k: synth.S1[k] for k in ("seed", "M", "N")})
+    dev = pkg.FastGoICP(tg, sr, 1e-4)
+    host = pkg.FastGoICP(tg, sr, 1e-4, device_queues=0)
+    dev.run(); host.run()
+    assert dev.counters.queue_fallbacks == 0
+    assert dev.get_best_error() < dev.sse_threshold and host.get_best_error() < host.sse_threshold
+    assert abs(dev.get_best_error() - host.get_best_error()) <= 1e-3 * host.get_best_error()
+    assert rot_angle(dev.optR, Rgt) <= 5e-3 and np.linalg.norm(dev.optT - tgt) <= 5e-3
+    dev.registration.close(); host.registration.close()
+
+
 def test_queue_round_width_and_continuous_flow(pkg, bunny_model, bunny_data10):
     """The two driver options above the device queues.  (1) The round width: a search may expand up to 128 nodes per
     round (trans_batch = 128 directly; adaptive_k widens the stragglers of a batch from 32 to 64 / 128) -- more

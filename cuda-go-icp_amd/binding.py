@@ -102,6 +102,7 @@ SYMBOLS = {
     "goicp_set_progress_callback": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     "goicp_probe_gather": (C.c_int, [_vp, C.c_int32, C.c_size_t, C.POINTER(C.c_double)]),
     "goicp_debug_kabsch": (C.c_int, [_fp, _fp]),
+    "goicp_debug_bounds_tile": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.POINTER(C.c_uint32)]),
     "goicp_debug_cache_hits": (C.c_int, [_vp, _fp, _fp, C.POINTER(C.c_int64)]),
     "goicp_create": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.POINTER(_vp)]),
     "goicp_destroy": (C.c_int, [_vp]),

@@ -337,6 +337,189 @@ __device__ __forceinline__ void bounds_work(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged DT tiles (north_star (a)): the bound evaluation for the DEEP expansions of one inner search.
+//
+// Late in a search the nodes an inner BnB expands are neighbours: the same rotation, translations a few voxels apart.
+// For a small patch of the cloud (64 consecutive points of the k-d order) ALL their lookups -- 64 points x 8 siblings x
+// up to 64 expansions = 32 768 -- then fall into one box of a few thousand voxels.  That box is copied from the bricked
+// grid into LDS once (a few hundred 128-byte lines, coalesced) and the lookups become ds_read_b32.
+//
+// Mapping: a workgroup = 4 wavefronts = one (search, point chunk); a LANE = one expansion of the search (its two sibling
+// translations per axis, delta, coeff live in registers); the 64 points of a sub-patch are dealt 16 to each wavefront and
+// broadcast from LDS (rotated once per sub-patch).  No cross-lane reduction at all: a lane owns the 16 sums of its
+// expansion over all the points its wavefront sees; the four wavefronts' sums are added in fixed order at the end.
+// Every per-point value is the same float expression as in bounds_work (voxel_fast / voxel_exact, the same clamp and
+// subtraction order); lookups that fall outside the staged box (or outside the grid) take dt_distance from global memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileFloats = 8192;                 // 32 KB: up to 128 bricks of 4x4x4 voxels
+constexpr int kTilePatch = 64;                    // points per staged box
+struct TileSeg { int off, n, rot; };              // a search's expansions parents[off .. off+n), n <= 64, one rotation
+
+__global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
+                                                          const ParentRec* __restrict__ parents, const TileSeg* __restrict__ segs, int nseg, int chunks,
+                                                          int chunk_pts, float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out,
+                                                          unsigned* __restrict__ stats)
+{
+	__shared__ float tile[kTileFloats];
+	__shared__ float4 rp[kTilePatch];             // R p of the sub-patch, w = |p|
+	static_assert(4 * 64 * 2 * kGroup <= kTileFloats, "the wavefront sums reuse the tile");
+	float (*wacc)[64][2 * kGroup] = reinterpret_cast<float (*)[64][2 * kGroup]>(tile);   // after the last sub-patch
+	__shared__ float tr[6];                       // translation range of the search's siblings: min xyz, max xyz
+	__shared__ int box[7];                        // brick origin bx0 by0 bz0, brick dims TX TY TZ, staged flag
+	__shared__ int red_i[4][6];
+	const int seg = blockIdx.x / chunks, chunk = blockIdx.x - seg * chunks;
+	if (seg >= nseg) return;
+	const TileSeg sg = segs[seg];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool live = lane < sg.n;
+	// this lane's expansion: corner + (bit)*w' + w'/2 per axis (load_group's float operations)
+	const ParentRec pr = parents[sg.off + (live ? lane : 0)];
+	const float w = pr.w / 2;
+	const float delta = (float)(1.732050808 / 2.0 * (double)w);
+	const SiblingSet ts{pr.x + w / 2, pr.x + w + w / 2, pr.y + w / 2, pr.y + w + w / 2, pr.z + w / 2, pr.z + w + w / 2};
+	const float coeff = pr.coeff;
+	const Rot9 R0 = rots[sg.rot];
+	if (wave == 0) {
+		float mn[3] = {ts.tx0, ts.ty0, ts.tz0}, mx[3] = {ts.tx1, ts.ty1, ts.tz1};
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			if (!live) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, 64)); }
+			if (lane == 0) { tr[k] = mn[k]; tr[3 + k] = mx[k]; }
+		}
+	}
+	float ub[kGroup], lb[kGroup];
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) { ub[c] = 0.f; lb[c] = 0.f; }
+	const int p0 = chunk * chunk_pts, p1 = p0 + chunk_pts < N ? p0 + chunk_pts : N;
+	__syncthreads();
+	for (int s0 = p0; s0 < p1; s0 += kTilePatch) {
+		// ---- the sub-patch: rotate, find the brick box of everything it can look up, stage it ----
+		const int np = p1 - s0 < kTilePatch ? p1 - s0 : kTilePatch;
+		if (threadIdx.x < kTilePatch) {
+			int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+			if ((int)threadIdx.x < np) {
+				const float4 p = src[s0 + threadIdx.x];
+				const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
+				const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
+				const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+				rp[threadIdx.x] = make_float4(rx, ry, rz, p.w);
+				const float r3[3] = {rx, ry, rz}, m3[3] = {dt.xmin_f, dt.ymin_f, dt.zmin_f};
+#pragma unroll
+				for (int k = 0; k < 3; k++) {      // a voxel of margin each way: the box only has to CONTAIN the exact indices
+					lo[k] = (int)floorf(((r3[k] + tr[k]) - m3[k]) * dt.scale_f + 0.5f) - 1;
+					hi[k] = (int)floorf(((r3[k] + tr[3 + k]) - m3[k]) * dt.scale_f + 0.5f) + 1;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = max(hi[k], __shfl_xor(hi[k], o, 64)); }
+			}
+			if (threadIdx.x == 0) {
+				int b0[3], nb[3];
+				bool ok = true;
+#pragma unroll
+				for (int k = 0; k < 3; k++) {
+					const int l = max(lo[k], 0) >> 2, h = min(hi[k], dt.V - 1) >> 2;
+					b0[k] = l; nb[k] = h - l + 1;
+					ok = ok && nb[k] > 0;
+				}
+				ok = ok && (long long)nb[0] * nb[1] * nb[2] * 64 <= kTileFloats;
+				box[0] = b0[0]; box[1] = b0[1]; box[2] = b0[2]; box[3] = nb[0]; box[4] = nb[1]; box[5] = nb[2]; box[6] = ok ? 1 : 0;
+				if (stats) atomicAdd(&stats[ok ? 0 : 1], 1u);
+			}
+		}
+		__syncthreads();
+		const int bx0 = box[0], by0 = box[1], bz0 = box[2], TX = box[3], TY = box[4], TZ = box[5];
+		const bool staged = box[6] != 0;
+		if (staged) {
+			const int n4 = TX * TY * TZ * 16;                             // float4 pieces
+			for (int idx = threadIdx.x; idx < n4; idx += 256) {
+				const int b = idx >> 4, part = idx & 15;
+				const int bx = b % TX, t2 = b / TX, by = t2 % TY, bz = t2 / TY;
+				const size_t gb = ((size_t)(bz0 + bz) * dt.VB + (by0 + by)) * dt.VB + (bx0 + bx);
+				reinterpret_cast<float4*>(tile)[idx] = reinterpret_cast<const float4*>(dt.grid)[gb * 16 + part];
+			}
+		}
+		__syncthreads();
+		// ---- every wavefront: its 16 points x this lane's 8 siblings ----
+		if (live)
+		for (int j = wave; j < np; j += 4) {
+			const float4 q = rp[j];                                       // same address in every lane: a broadcast read
+			const float qx[2] = {q.x + ts.tx0, q.x + ts.tx1}, qy[2] = {q.y + ts.ty0, q.y + ts.ty1}, qz[2] = {q.z + ts.tz0, q.z + ts.tz1};
+			bool risky = false;
+			int ix[2], iy[2], iz[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				ix[k] = voxel_fast(qx[k], dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+				iy[k] = voxel_fast(qy[k], dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
+				iz[k] = voxel_fast(qz[k], dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
+			}
+			if (risky) {
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+				}
+			}
+			unsigned fx[2], fy[2], fz[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const int ax = (ix[k] >> 2) - bx0, ay = (iy[k] >> 2) - by0, az = (iz[k] >> 2) - bz0;
+				fx[k] = staged && (unsigned)ax < (unsigned)TX ? ((unsigned)ax << 6) | ((unsigned)ix[k] & 3u) : kOutside;
+				fy[k] = staged && (unsigned)ay < (unsigned)TY ? ((unsigned)(ay * TX) << 6) | (((unsigned)iy[k] & 3u) << 2) : kOutside;
+				fz[k] = staged && (unsigned)az < (unsigned)TZ ? ((unsigned)(az * TX * TY) << 6) | (((unsigned)iz[k] & 3u) << 4) : kOutside;
+			}
+			const float rho = coeff * q.w;
+#pragma unroll
+			for (int c = 0; c < kGroup; c++) {
+				const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
+				float v;
+				if (e < kOutside) v = tile[e];
+				else v = dt_distance<1>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);     // outside the box or the grid
+				v = v - rho;
+				const float m = v < 0.f ? 0.f : v;
+				ub[c] += m * m;
+				const float dis = fmaxf(m - delta, 0.f);
+				lb[c] += dis * dis;
+			}
+		}
+		__syncthreads();                                                  // the box is restaged by the next sub-patch
+	}
+	// ---- the four wavefronts' sums, in wavefront order ----
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) { wacc[wave][lane][c] = ub[c]; wacc[wave][lane][kGroup + c] = lb[c]; }
+	__syncthreads();
+	for (int idx = threadIdx.x; idx < sg.n * 2 * kGroup; idx += 256) {
+		const int e = idx >> 4, k = idx & 15;
+		const float s = ((wacc[0][e][k] + wacc[1][e][k]) + wacc[2][e][k]) + wacc[3][e][k];
+		const int group = sg.off + e;
+		if (chunks == 1) (k < kGroup ? ub_out : lb_out)[group * kGroup + (k & (kGroup - 1))] = s;
+		else scratch[((size_t)group * chunks + chunk) * (2 * kGroup) + k] = s;
+	}
+}
+
+__global__ void bounds_finalize(const float* __restrict__ scratch, int B, int groups, int chunks, float* __restrict__ ub_out, float* __restrict__ lb_out);
+// test / measurement entry: nseg searches of n <= 64 expansions each (segment i = parents[i*n .. i*n+n), rotation i)
+hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const void* segs, int nseg, int n,
+                              int chunks, float* scratch, float* ub, float* lb, unsigned* stats, hipStream_t stream)
+{
+	if (dt.layout != 1 || n < 1 || n > 64 || nseg < 1 || chunks < 1) return hipErrorInvalidValue;
+	int cp = (N + chunks - 1) / chunks;
+	cp = (cp + kTilePatch - 1) / kTilePatch * kTilePatch;
+	hipLaunchKernelGGL(bounds_tile_kernel, dim3(nseg * chunks), dim3(256), 0, stream, src, N, dt, rots, parents, static_cast<const TileSeg*>(segs), nseg, chunks, cp,
+	                   scratch, ub, lb, stats);
+	if (chunks > 1) {
+		const int groups = nseg * n, t = groups * 2 * kGroup;
+		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, groups * kGroup, groups, chunks, ub, lb);
+	}
+	return hipGetLastError();
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,

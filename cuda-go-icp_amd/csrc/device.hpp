@@ -120,6 +120,10 @@ hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QPar
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
                                int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream);
 size_t bounds_queue_scratch_floats(int max_groups);
+// LDS-staged DT tiles for the deep expansions of a search (device.hip bounds_tile_kernel): nseg segments of n <= 64 expansions,
+// segs = nseg x {int off, int n, int rot}; stats (may be null): [0] sub-patches staged, [1] sub-patches whose box did not fit
+hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const void* segs, int nseg, int n,
+                              int chunks, float* scratch, float* ub, float* lb, unsigned* stats, hipStream_t stream);
 
 // ---- ICP ------------------------------------------------------------------------------------
 // Device-resident state of the ICP loop (ICP3D<float>::Run, jly_icp3d.hpp:181-295).  One

@@ -841,6 +841,59 @@ void debug_kabsch(const float H[9], float R[9])
 	HIPCHK(hipMemcpy(R, buf.p + 9, sizeof(float) * 9, hipMemcpyDeviceToHost));
 }
 
+void Engine::debug_bounds_tile(const float* rots9, const float* parents4, int nseg, int n, int level, int chunks, float* ub_tile, float* lb_tile,
+                               float* ub_direct, float* lb_direct, float ms[2], unsigned stats[2])
+{
+	DeviceGuard guard(dev_);
+	if (nseg < 1 || n < 1 || n > 64 || chunks < 1) throw std::invalid_argument("goicp: debug_bounds_tile: bad shape");
+	const size_t G = (size_t)nseg * n, B = G * kGroup;
+	struct Seg { int off, n, rot; };
+	std::vector<ParentRec> par(G);
+	std::vector<Seg> segs((size_t)nseg);
+	const float coeff = rot_coeff(level);
+	for (int i = 0; i < nseg; i++) {
+		segs[(size_t)i] = Seg{i * n, n, i};
+		for (int e = 0; e < n; e++) {
+			const float* q = parents4 + ((size_t)i * n + e) * 4;
+			par[(size_t)i * n + e] = ParentRec{q[0], q[1], q[2], q[3], coeff, i};
+		}
+	}
+	int g2 = 0, c2 = 0;
+	const size_t sc_direct = bounds_scratch_floats((int)B, (int)N_, &g2, &c2), sc_tile = G * (size_t)chunks * 2 * kGroup;
+	DevBuf<ParentRec> d_par(G);
+	DevBuf<Seg> d_seg((size_t)nseg);
+	DevBuf<Rot9> d_rot((size_t)nseg);
+	DevBuf<float> d_out(4 * B), d_sc(std::max(sc_direct, sc_tile) + 64);
+	DevBuf<unsigned> d_stats(2);
+	HIPCHK(hipMemcpyAsync(d_par.p, par.data(), sizeof(ParentRec) * G, hipMemcpyHostToDevice, stream_));
+	HIPCHK(hipMemcpyAsync(d_seg.p, segs.data(), sizeof(Seg) * (size_t)nseg, hipMemcpyHostToDevice, stream_));
+	HIPCHK(hipMemcpyAsync(d_rot.p, rots9, sizeof(Rot9) * (size_t)nseg, hipMemcpyHostToDevice, stream_));
+	HIPCHK(hipMemsetAsync(d_stats.p, 0, sizeof(unsigned) * 2, stream_));
+	float* t_ub = d_out.p; float* t_lb = d_out.p + B; float* r_ub = d_out.p + 2 * B; float* r_lb = d_out.p + 3 * B;
+	const int reps = 5;
+	for (int pass = 0; pass < 2; pass++) {              // pass 0 warms up (and counts the sub-patches), pass 1 is timed
+		HIPCHK(hipEventRecord(ev0_, stream_));
+		for (int r = 0; r < (pass ? reps : 1); r++)
+			HIPCHK(launch_bounds_tile(d_src_, (int)N_, dt_, d_rot.p, d_par.p, d_seg.p, nseg, n, chunks, d_sc.p, t_ub, t_lb, pass ? nullptr : d_stats.p, stream_));
+		HIPCHK(hipEventRecord(ev1_, stream_));
+		HIPCHK(hipEventSynchronize(ev1_));
+		if (pass) { HIPCHK(hipEventElapsedTime(&ms[0], ev0_, ev1_)); ms[0] /= reps; }
+	}
+	for (int pass = 0; pass < 2; pass++) {
+		HIPCHK(hipEventRecord(ev0_, stream_));
+		for (int r = 0; r < (pass ? reps : 1); r++)
+			HIPCHK(launch_bounds(d_src_, (int)N_, dt_, d_rot.p, nullptr, d_par.p, (int)B, d_sc.p, r_ub, r_lb, stream_));
+		HIPCHK(hipEventRecord(ev1_, stream_));
+		HIPCHK(hipEventSynchronize(ev1_));
+		if (pass) { HIPCHK(hipEventElapsedTime(&ms[1], ev0_, ev1_)); ms[1] /= reps; }
+	}
+	HIPCHK(hipMemcpy(ub_tile, t_ub, sizeof(float) * B, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(lb_tile, t_lb, sizeof(float) * B, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(ub_direct, r_ub, sizeof(float) * B, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(lb_direct, r_lb, sizeof(float) * B, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(stats, d_stats.p, sizeof(unsigned) * 2, hipMemcpyDeviceToHost));
+}
+
 long long Engine::debug_cache_hits(const float R[9], const float t[3])
 {
 	// two scoring passes at the same pose: the second one's queries should all hit the neighbour cache

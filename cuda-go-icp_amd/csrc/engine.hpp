@@ -101,7 +101,11 @@ public:
 	void icp_step();   // one ICP iteration on the engine's current pose (ICP::kdTreeGPUStep)
 	// measured ceiling of the gather path (4-byte loads into the resident DT): lookups/s; mode 0 coalesced, 1 divergent
 	double probe_gather(int mode, size_t window_bytes);
-	long long debug_cache_hits(const float R[9], const float t[3]);   // queries of a repeated pass that skipped the tree walk (-1: cache off)
+	long long debug_cache_hits(const float R[9], const float t[3]);
+	// measurement / test: the 8 children of nseg x n expansions (segment i: rotation i, parents4[(i*n + e)*4 ..] = corner xyz + width) through
+	// the LDS-tile kernel and through the direct kernel; out arrays hold 8*nseg*n floats each; ms[0] tile, ms[1] direct (per launch)
+	void debug_bounds_tile(const float* rots9, const float* parents4, int nseg, int n, int level, int chunks, float* ub_tile, float* lb_tile,
+	                       float* ub_direct, float* lb_direct, float ms[2], unsigned stats[2]);   // queries of a repeated pass that skipped the tree walk (-1: cache off)
 
 	// ---- registration ----
 	void run();                                  // FastGoICP::run / GoICP::Register

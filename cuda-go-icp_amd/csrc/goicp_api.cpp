@@ -209,6 +209,13 @@ int goicp_debug_cache_hits(goicp_handle h, const float R[9], const float t[3], i
 	return guarded([&] { *hits = h->e->debug_cache_hits(R, t); });
 }
 
+int goicp_debug_bounds_tile(goicp_handle h, const float* rots9, const float* parents4, int32_t nseg, int32_t n, int32_t level, int32_t chunks,
+                            float* ub_tile, float* lb_tile, float* ub_direct, float* lb_direct, float ms[2], uint32_t stats[2])
+{
+	REQUIRE(h && rots9 && parents4 && ub_tile && lb_tile && ub_direct && lb_direct && ms && stats);
+	return guarded([&] { h->e->debug_bounds_tile(rots9, parents4, nseg, n, level, chunks, ub_tile, lb_tile, ub_direct, lb_direct, ms, stats); });
+}
+
 int goicp_debug_kabsch(const float H[9], float R[9])
 {
 	REQUIRE(H && R);

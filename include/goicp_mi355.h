@@ -334,6 +334,15 @@ int goicp_register_multi_gpu(const goicp_params* params, const float* target_xyz
  * src/goicp/jly_icp3d.hpp:266-285) on a caller-supplied H (row-major), on the current device; test-only. */
 int goicp_probe_gather(goicp_handle h, int32_t mode, size_t window_bytes, double* lookups_per_s);
 int goicp_debug_kabsch(const float H[9], float R[9]);
+/*
+ * goicp_debug_bounds_tile (measurement / test): the cube bounds of the 8 children of nseg x n translation nodes (n <= 64; segment i
+ * uses rotation rots9[9*i..], its nodes parents4[(i*n + e)*4..] = corner xyz + width, rotation level `level`) evaluated twice:
+ * by the LDS-staged-tile kernel (north_star (a): the DT box a 64-point patch can reach under all the segment's translations is copied
+ * to LDS once) and by the direct gather kernel of the search (registration.cu:27-60's role).  ub/lb arrays: 8*nseg*n floats each;
+ * ms[0] / ms[1]: milliseconds per launch, tile / direct; stats[0] / stats[1]: 64-point patches staged / too large to stage.
+ */
+int goicp_debug_bounds_tile(goicp_handle h, const float* rots9, const float* parents4, int32_t nseg, int32_t n, int32_t level, int32_t chunks,
+                            float* ub_tile, float* lb_tile, float* ub_direct, float* lb_direct, float ms[2], uint32_t stats[2]);
 /* diagnostics of the ICP pass's neighbour cache: two scoring passes at (R, t); *hits = queries of the second pass that
  * skipped the tree walk (-1 when the cache is off) */
 int goicp_debug_cache_hits(goicp_handle h, const float R[9], const float t[3], int64_t* hits);

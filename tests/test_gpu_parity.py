@@ -1130,6 +1130,45 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
         e.registration.close()
 
 
+def test_lds_tile_kernel_matches_direct_kernel(pkg, bunny_model, bunny_data):
+    """north_star (a) names LDS-staged DT tiles; bounds_tile_kernel is that design for the deep expansions of one search (a
+    lane = one expansion, the DT box a 64-point patch can reach is copied to LDS once; lookups outside the box or the grid
+    read global memory).  It is a measurement vehicle (tools/tile_probe.py, DESIGN 3.6: 1.2x at best), not on the search
+    path; this test keeps it honest: same per-point arithmetic as the direct kernel, so the bounds agree to summation
+    order, for deep blocks (everything staged), shallow ones (nothing fits: every lookup takes the fallback) and ragged
+    segment sizes."""
+    import ctypes as C
+    from cuda_go_icp_amd import binding as B
+    reg = pkg.Registration(bunny_model, bunny_data, 1e-3)
+    lib, h = reg._lib, reg.handle
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(11)
+    for depth, n, chunks in ((8, 64, 4), (6, 64, 1), (3, 64, 3), (7, 17, 2), (9, 1, 1)):
+        nseg = 6
+        w = np.float32(1.0 / (1 << depth))
+        rots = np.stack([pkg.fgoicp.rodrigues(rng.uniform(-2.0, 2.0, 3)) for _ in range(nseg)]).astype(np.float32).reshape(-1)
+        par = np.zeros((nseg, n, 4), np.float32)
+        for i in range(nseg):
+            c0 = (np.floor(rng.uniform(-0.3, 0.3, 3) / w) * w).astype(np.float32)
+            for k in range(n):
+                par[i, k] = (c0[0] + (k & 3) * w, c0[1] + ((k >> 2) & 3) * w, c0[2] + ((k >> 4) & 3) * w, w)
+        Bc = nseg * n * 8
+        out = [np.zeros(Bc, np.float32) for _ in range(4)]
+        ms = (C.c_float * 2)(); st = (C.c_uint32 * 2)()
+        B.check(lib.goicp_debug_bounds_tile(h, fp(rots), fp(par.reshape(-1)), nseg, n, 5, chunks, fp(out[0]), fp(out[1]), fp(out[2]), fp(out[3]), ms, st))
+        for t, d in ((out[0], out[2]), (out[1], out[3])):
+            assert np.all(np.abs(t - d) <= 3e-6 * np.maximum(np.abs(d), 1e-3)), (depth, n, float(np.max(np.abs(t - d))))
+        assert st[0] + st[1] > 0
+        if depth >= 8:
+            assert st[0] > 10 * st[1]                  # deep blocks: (nearly) every patch is staged
+        if depth <= 3:
+            assert st[0] == 0                          # 43-voxel sibling spacing: no box fits, the fallback carries it all
+    # the direct kernel through this entry is the search's kernel: same numbers as goicp_eval_bounds
+    ub, lb = reg.eval_bounds(rots[:9].reshape(3, 3), np.array([[par[0, 0, 0] + par[0, 0, 3] / 4, par[0, 0, 1] + par[0, 0, 3] / 4, par[0, 0, 2] + par[0, 0, 3] / 4, par[0, 0, 3] / 2]], np.float32), 5)
+    assert abs(ub[0] - out[2][0]) <= 1e-6 * max(abs(ub[0]), 1e-3) and abs(lb[0] - out[3][0]) <= 1e-6 * max(abs(lb[0]), 1e-3)
+    reg.close()
+
+
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     """Params::bounds_fp16 (opt-in, not the parity path): the BnB bounds read a half-precision copy of the bricked DT
     rounded toward zero.  Against the fp32 engine on the same cubes: every lower bound is <= the fp32 one (still a valid

@@ -8,7 +8,7 @@ _LIB = None
 
 OK = 0
 STATUS = {-1: "GOICP_ERR_INVALID", -2: "GOICP_ERR_IO", -3: "GOICP_ERR_CONFIG", -4: "GOICP_ERR_NO_DEVICE",
-          -5: "GOICP_ERR_DEVICE", -6: "GOICP_ERR_INTERNAL"}
+          -5: "GOICP_ERR_DEVICE", -6: "GOICP_ERR_INTERNAL", -7: "GOICP_ERR_TIMEOUT", -8: "GOICP_ERR_PEER"}
 PATH_MAX = 1024
 
 
@@ -68,7 +68,12 @@ class CCommOps(C.Structure):
 
 
 class CShardStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("steps", "exchanges", "broadcasts", "donations", "donated_cubes")] + [("best_sse", C.c_float)]
+    _fields_ = [(n, C.c_int64) for n in ("steps", "exchanges", "broadcasts", "donations", "donated_cubes", "steps_idle")] + \
+               [("wait_ms", C.c_double), ("step_ms", C.c_double), ("best_sse", C.c_float), ("failed_rank", C.c_int32)]
+
+
+class CShardOptions(C.Structure):
+    _fields_ = [("rot_pops_per_step", C.c_int32), ("rebalance", C.c_int32), ("stale_exchange", C.c_int32), ("reserved", C.c_int32)]
 
 
 _fpp = C.POINTER(C.c_float)
@@ -135,6 +140,10 @@ SYMBOLS = {
     "goicp_register_end": (C.c_int, [_vp]),
     "goicp_run_sharded": (C.c_int, [C.POINTER(CShardEngineOps), C.POINTER(CCommOps), C.c_int32, C.c_int32, C.POINTER(CShardStats)]),
     "goicp_register_sharded": (C.c_int, [_vp, C.POINTER(CCommOps), C.c_int32, C.c_int32, C.POINTER(CShardStats)]),
+    "goicp_shard_options_default": (None, [C.POINTER(CShardOptions)]),
+    "goicp_run_sharded_opt": (C.c_int, [C.POINTER(CShardEngineOps), C.POINTER(CCommOps), C.POINTER(CShardOptions), C.POINTER(CShardStats)]),
+    "goicp_register_sharded_opt": (C.c_int, [_vp, C.POINTER(CCommOps), C.POINTER(CShardOptions), C.POINTER(CShardStats)]),
+    "goicp_comm_set_timeout_ms": (C.c_int, [C.POINTER(CCommOps), C.c_int32]),
     "goicp_thread_comm_create": (C.c_int, [C.c_int32, C.POINTER(CCommOps)]),
     "goicp_thread_comm_destroy": (C.c_int, [C.POINTER(CCommOps)]),
     "goicp_rccl_unique_id": (C.c_int, [C.c_char_p]),

@@ -1,7 +1,12 @@
 // goicp_cli: headless replacement for the reference's viewer main (src/main.cpp:14-187).  Takes the
-// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N]
+// reference's .toml unchanged:  goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N] [--reference-root]
 //   --ranks N   (modes 3/4) shard the rotation-cube search over N GPUs of this node: N engines (device r for rank r),
 //               N host threads, RCCL all-reduce / broadcast over xGMI (goicp_register_multi_gpu)
+//   --reference-root   search the reference CPU path's roots ([-pi,pi]^3 x [-0.5,0.5]^3, src/goicp/jly_goicp.cpp:44-53) and
+//               ignore the TOML's [params.rotation] / [params.translation] / search_depth -- which the reference declares
+//               (src/common.h:157-169) but never applies.  WITHOUT this flag the ranges ARE applied (the configs ship
+//               translation +-1.0: a root of width 2, 8x the volume of the CPU path's), so node counts and times on the
+//               reference's own .toml files are then not comparable with the strict-order goldens: use the flag for parity runs.
 //   modes 0/1/2 (plain ICP, src/main.cpp:99-110): N ICP iterations (the reference iterates forever; default 50)
 //   modes 3/4   (Go-ICP,   src/main.cpp:111-141): full registration
 // Prints the result the way the reference logs it and writes io.output (output.toml) when set.
@@ -28,8 +33,8 @@ static std::string resolve(const std::string& p, const std::string& toml)
 
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N]\n"); return 2; }
-	int iters = 50, verbose = 0, ranks = 1;
+	if (argc < 2) { std::fprintf(stderr, "usage: goicp_cli <config.toml> [--iters N] [--trim-fraction F] [--verbose] [--seed S] [--ranks N] [--reference-root]\n"); return 2; }
+	int iters = 50, verbose = 0, ranks = 1, reference_root = 0;
 	float trim_fraction = 0.f;   // the TOML's `trim = true` carries no fraction (the reference ignores it): given here
 	unsigned long long seed = 0;
 	for (int i = 2; i < argc; i++) {
@@ -38,6 +43,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--trim-fraction") && i + 1 < argc) trim_fraction = (float)std::atof(argv[++i]);
 		else if (!std::strcmp(argv[i], "--verbose")) verbose = 1;
 		else if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = std::atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "--reference-root")) reference_root = 1;
 	}
 	try {
 		Config config(argv[1]);
@@ -50,6 +56,7 @@ int main(int argc, char** argv)
 		goicp_params_from_config(&config.raw, &p);      // mse_threshold + the [params.rotation] / [params.translation] search ranges
 		p.verbose = verbose;
 		p.trim_fraction = trim_fraction;
+		if (reference_root) { p.use_rot_range = 0; p.use_trans_range = 0; p.rot_search_depth = 0; p.trans_search_depth = 0; }
 		if (ranks > 1 && config.mode > 2) {
 			// the sharded search: one engine per GPU inside the library, rank 0's engine comes back for the result
 			p.mse_threshold = config.mse_threshold;
@@ -58,10 +65,13 @@ int main(int argc, char** argv)
 			check(goicp_register_multi_gpu(&p, &target[0].x, target.size(), &source[0].x, source.size(), ranks, 8, &h0, st.data()));
 			goicp_result r;
 			check(goicp_poll(h0, &r));
-			std::printf("Searching over (%d GPUs)! Best Error: %.7g  (MSE %.7g)\n", ranks, r.best_sse, r.best_sse / (float)source.size());
+			float sse_thr = 0.f; int32_t inliers = (int32_t)source.size();
+			check(goicp_thresholds(h0, &sse_thr, &inliers));         // MSE over the inliers, as output.toml (jly_goicp.cpp:198-208)
+			std::printf("Searching over (%d GPUs)! Best Error: %.7g  (MSE %.7g)\n", ranks, r.best_sse, r.best_sse / (float)inliers);
 			for (int k = 0; k < ranks; k++)
-				std::printf("rank %d: %lld steps, %lld exchanges, %lld pose broadcasts, %lld donations (%lld cubes)\n", k, (long long)st[(size_t)k].steps,
-				            (long long)st[(size_t)k].exchanges, (long long)st[(size_t)k].broadcasts, (long long)st[(size_t)k].donations, (long long)st[(size_t)k].donated_cubes);
+				std::printf("rank %d: %lld steps (%lld idle), %lld exchanges, %lld pose broadcasts, %lld donations (%lld cubes), step %.1f ms, waiting in collectives %.1f ms\n",
+				            k, (long long)st[(size_t)k].steps, (long long)st[(size_t)k].steps_idle, (long long)st[(size_t)k].exchanges, (long long)st[(size_t)k].broadcasts,
+				            (long long)st[(size_t)k].donations, (long long)st[(size_t)k].donated_cubes, st[(size_t)k].step_ms, st[(size_t)k].wait_ms);
 			std::printf("Optimal Rotation Matrix:\n");
 			for (int i = 0; i < 3; i++) std::printf("%12.7f %12.7f %12.7f\n", r.optR[3 * i], r.optR[3 * i + 1], r.optR[3 * i + 2]);
 			std::printf("Optimal Translation Vector:\n%12.7f\n%12.7f\n%12.7f\n", r.optT[0], r.optT[1], r.optT[2]);
@@ -81,7 +91,9 @@ int main(int argc, char** argv)
 		} else {
 			engine.run();
 			check(goicp_poll(h, &r));
-			std::printf("Searching over! Best Error: %.7g  (MSE %.7g)\n", r.best_sse, r.best_sse / (float)source.size());
+			float sse_thr = 0.f; int32_t inliers = (int32_t)source.size();
+			check(goicp_thresholds(h, &sse_thr, &inliers));          // MSE over the inliers, as output.toml (jly_goicp.cpp:198-208)
+			std::printf("Searching over! Best Error: %.7g  (MSE %.7g)\n", r.best_sse, r.best_sse / (float)inliers);
 			std::printf("Total Translation Nodes Searched: %lld\nTotal Rotation Nodes Searched: %lld\n",
 			            (long long)r.counters.trans_pops, (long long)r.counters.rot_pops);
 			std::printf("cube bounds %lld in %.1f ms (DT build %.1f ms)\n", (long long)r.counters.cubes, r.register_ms, r.dt_build_ms);

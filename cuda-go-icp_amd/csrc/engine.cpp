@@ -165,7 +165,13 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			w = std::max(w, hi[k] - lo[k]);
 		}
 		if (!(w > 0.f)) w = 1e-6f;          // a point range: one tiny cube
-		root->x = (lo[0] + hi[0]) / 2 - w / 2; root->y = (lo[1] + hi[1]) / 2 - w / 2; root->z = (lo[2] + hi[2]) / 2 - w / 2;
+		// An axis of zero width (rotation about one axis only, a fixed translation component): centred, its value would sit
+		// exactly on the first split plane, and the strict in_box test would drop BOTH children -- the search would end
+		// after one pop with the initial ICP pose.  Such an axis is placed a third of the way into the root instead: a
+		// third is not a dyadic fraction, so the value is interior to exactly one cube at every level.
+		float c[3];
+		for (int k = 0; k < 3; k++) c[k] = hi[k] > lo[k] ? (lo[k] + hi[k]) / 2 - w / 2 : lo[k] - w / 3;
+		root->x = c[0]; root->y = c[1]; root->z = c[2];
 		root->w = w;
 	};
 	if (p_.use_rot_range) {
@@ -1445,7 +1451,9 @@ int Engine::flow_step(int max_rot_pops)
 	auto unhandled = [&] { size_t n = 0; for (const Flight& f : flights_) n += f.handled ? 0 : 1; return n; };
 	while (!early_exit_ && !cancel_.load()) {
 		// ---- admit the next batch of rotation parents when the running searches are few ----
-		const int P = std::max(1, std::min(p_.rot_batch, rot_ramp_));
+		// at most kFlowSearches / 16 parents per admission: a batch needs 16 search slots per parent, and with a larger P the
+		// admission test below could never pass even with every slot free (rot_batch > 128: the loop would spin forever)
+		const int P = std::max(1, std::min(std::min(p_.rot_batch, rot_ramp_), kFlowSearches / 16));
 		if (!converged_ && !queue_.empty() && pops < max_rot_pops && flow_active_ <= (flights_.empty() ? kFlowSearches : p_.flow) &&
 		    free_search_.size() >= (size_t)16 * P && free_rot_.size() >= (size_t)8 * P) {
 			std::vector<Node> parents;
@@ -1575,6 +1583,9 @@ StepStatus Engine::register_step(int max_rot_pops)
 	if (!converged_ && !early_exit_)
 		for (const Flight& f : flights_) st.frontier_lb = std::min(st.frontier_lb, f.kid.parent_lb);   // children still in flight stand for their parents
 	st.rot_pops = cnt_.rot_pops;
+	// a step that neither popped a rotation node nor has searches in flight, with work still queued, would make every
+	// caller loop (Engine::run, run_sharded) spin forever with the GPU idle: report it instead
+	if (!st.finished && pops == 0 && flights_.empty()) throw std::logic_error("goicp: register_step made no progress with a non-empty rotation queue");
 	return st;
 }
 

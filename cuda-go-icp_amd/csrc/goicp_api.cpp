@@ -9,24 +9,13 @@
 #include <thread>
 #include <vector>
 
+#include "comm.hpp"
 #include "config_io.hpp"
 #include "engine.hpp"
 
 struct goicp_engine {
 	goicp::Engine* e;
 };
-
-namespace goicp {
-int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, int rot_pops_per_step, int rebalance, goicp_shard_stats* stats);
-int thread_comm_create(int world, goicp_comm_ops* out);
-void thread_comm_destroy(goicp_comm_ops* comm);
-int rccl_unique_id(char id128[GOICP_RCCL_ID_BYTES]);
-int rccl_comm_create(const char id128[GOICP_RCCL_ID_BYTES], int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
-int rccl_comm_wrap(void* nccl_comm, int32_t rank, int32_t world, int32_t device, goicp_comm_ops* out);
-int rccl_comm_destroy(goicp_comm_ops* comm);
-int rccl_comm_init_all(int world, void** comms);
-void rccl_comm_destroy_raw(void* comm);
-}  // namespace goicp
 
 namespace {
 
@@ -420,32 +409,64 @@ int eo_pose(void* c, float* sse, float R[9], float t[3])
 	});
 }
 int eo_offer(void* c, float sse, const float R[9], const float t[3]) { return guarded([&] { E(c)->offer_global_best(sse, R, t); }); }
-int eo_qsize(void* c, int32_t* n) { *n = E(c)->queue_size(); return GOICP_OK; }
+int eo_qsize(void* c, int32_t* n) { return guarded([&] { *n = E(c)->queue_size(); }); }
 int eo_donate(void* c, int32_t max_nodes, float* nodes7, int32_t* n) { return guarded([&] { *n = E(c)->donate(max_nodes, nodes7); }); }
 int eo_receive(void* c, const float* nodes7, int32_t n) { return guarded([&] { E(c)->receive(nodes7, n); }); }
 int eo_end(void* c) { return guarded([&] { E(c)->register_end(); }); }
 }  // namespace
 
-int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
-                      goicp_shard_stats* stats)
+void goicp_shard_options_default(goicp_shard_options* out)
 {
-	REQUIRE(engine && comm && engine->begin && engine->step && engine->pose && engine->offer && engine->queue_size && engine->donate &&
-	        engine->receive && engine->end && comm->allreduce_min_u64 && comm->bcast);
+	if (!out) return;
+	out->rot_pops_per_step = 8; out->rebalance = 1; out->stale_exchange = 0; out->reserved = 0;
+}
+
+int goicp_run_sharded_opt(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats)
+{
+	REQUIRE(engine && comm && opt && engine->begin && engine->step && engine->pose && engine->offer && engine->queue_size && engine->donate &&
+	        engine->receive && engine->end && comm->allreduce_min_u64 && comm->bcast && opt->rot_pops_per_step >= 1);
+	g_err.clear();                  // a message left by an earlier, unrelated failure on this thread must not be reported for this run
 	int rc = GOICP_ERR_INTERNAL;
-	const int g = guarded([&] { rc = goicp::run_sharded(engine, comm, rot_pops_per_step, rebalance, stats); });
+	const int g = guarded([&] { rc = goicp::run_sharded(engine, comm, opt, stats); });
 	if (g != GOICP_OK) return g;
-	if (rc != GOICP_OK && g_err.empty()) g_err = "sharded registration: a callback failed";
+	if (rc == GOICP_ERR_TIMEOUT) g_err = "sharded registration: a collective missed the communicator's deadline (a rank is lost); exit non-zero";
+	else if (rc == GOICP_ERR_PEER) g_err = "sharded registration: rank " + std::to_string(stats ? stats->failed_rank : -1) + " reported a failure";
+	else if (rc != GOICP_OK && g_err.empty()) g_err = "sharded registration: a callback failed";
 	return rc;
 }
 
-int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance, goicp_shard_stats* stats)
+int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
+                      goicp_shard_stats* stats)
 {
-	REQUIRE(h && comm);
+	goicp_shard_options o;
+	goicp_shard_options_default(&o);
+	o.rot_pops_per_step = rot_pops_per_step; o.rebalance = rebalance;
+	return goicp_run_sharded_opt(engine, comm, &o, stats);
+}
+
+int goicp_register_sharded_opt(goicp_handle h, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats)
+{
+	REQUIRE(h && comm && opt);
 	goicp_shard_engine_ops eo{};
 	eo.ctx = h; eo.sse_threshold = h->e->sse_threshold();
 	eo.begin = eo_begin; eo.step = eo_step; eo.pose = eo_pose; eo.offer = eo_offer; eo.queue_size = eo_qsize;
 	eo.donate = eo_donate; eo.receive = eo_receive; eo.end = eo_end;
-	return goicp_run_sharded(&eo, comm, rot_pops_per_step, rebalance, stats);
+	return goicp_run_sharded_opt(&eo, comm, opt, stats);
+}
+
+int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance, goicp_shard_stats* stats)
+{
+	goicp_shard_options o;
+	goicp_shard_options_default(&o);
+	o.rot_pops_per_step = rot_pops_per_step; o.rebalance = rebalance;
+	return goicp_register_sharded_opt(h, comm, &o, stats);
+}
+
+int goicp_comm_set_timeout_ms(goicp_comm_ops* comm, int32_t timeout_ms)
+{
+	REQUIRE(comm && comm->ctx && timeout_ms >= 1);
+	const int rc = goicp::comm_set_timeout_ms(comm, timeout_ms);
+	return rc == GOICP_OK ? rc : fail(rc, "goicp_comm_set_timeout_ms: not a communicator made by this library");
 }
 
 int goicp_thread_comm_create(int32_t world, goicp_comm_ops* out)

@@ -3,6 +3,7 @@
 // communicator (shard.cpp), the threaded k-d build (kdtree.cpp: parallel_tasks), the TOML / PLY / TXT readers and
 // the result writers (config_io.cpp) -- and drives them from several threads.  Run on the CPU only, never on the GPU box.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,15 +13,9 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/goicp_mi355.h"
+#include "comm.hpp"
 #include "config_io.hpp"
 #include "engine.hpp"
-
-namespace goicp {
-int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, int rot_pops_per_step, int rebalance, goicp_shard_stats* stats);
-int thread_comm_create(int world, goicp_comm_ops* out);
-void thread_comm_destroy(goicp_comm_ops* comm);
-}  // namespace goicp
 
 namespace {
 
@@ -32,6 +27,8 @@ int g_fail = 0;
 // the same best value as a single rank.
 struct ToyEngine {
 	struct Cube { float lb; int id, depth; bool operator<(const Cube& o) const { return lb > o.lb; } };
+	int fail_at_step = -1, fail_what = 0, steps = 0;     // fault injection: 1 step, 2 offer, 3 donate, 4 begin
+	bool ended = false;
 	std::priority_queue<Cube> q;
 	float best = 1e9f, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
 	int rank = 0, world = 1;
@@ -61,8 +58,19 @@ struct ToyEngine {
 		s->frontier_lb = q.empty() ? INFINITY : q.top().lb; s->rot_pops = pops;
 	}
 };
-int te_begin(void* c, int32_t r, int32_t w) { static_cast<ToyEngine*>(c)->begin(r, w); return 0; }
-int te_step(void* c, int32_t m, goicp_step_status* s) { static_cast<ToyEngine*>(c)->step(m, s); return 0; }
+int te_begin(void* c, int32_t r, int32_t w)
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	e->begin(r, w);
+	return e->fail_what == 4 ? GOICP_ERR_DEVICE : 0;
+}
+int te_step(void* c, int32_t m, goicp_step_status* s)
+{
+	ToyEngine* e = static_cast<ToyEngine*>(c);
+	if (e->fail_what == 1 && ++e->steps == e->fail_at_step) return GOICP_ERR_DEVICE;
+	e->step(m, s);
+	return 0;
+}
 int te_pose(void* c, float* sse, float R[9], float t[3])
 {
 	ToyEngine* e = static_cast<ToyEngine*>(c);
@@ -72,6 +80,7 @@ int te_pose(void* c, float* sse, float R[9], float t[3])
 int te_offer(void* c, float sse, const float*, const float t[3])
 {
 	ToyEngine* e = static_cast<ToyEngine*>(c);
+	if (e->fail_what == 2) return GOICP_ERR_INTERNAL;
 	if (sse < e->best) { e->best = sse; std::memcpy(e->t, t, sizeof(e->t)); }
 	return 0;
 }
@@ -79,6 +88,7 @@ int te_qsize(void* c, int32_t* n) { *n = (int32_t)static_cast<ToyEngine*>(c)->q.
 int te_donate(void* c, int32_t max_nodes, float* nodes7, int32_t* n)
 {
 	ToyEngine* e = static_cast<ToyEngine*>(c);
+	if (e->fail_what == 3) return GOICP_ERR_DEVICE;
 	std::vector<ToyEngine::Cube> all;
 	while (!e->q.empty()) { all.push_back(e->q.top()); e->q.pop(); }
 	*n = 0;
@@ -94,9 +104,18 @@ int te_receive(void* c, const float* nodes7, int32_t n)
 	for (int i = 0; i < n; i++) e->q.push(ToyEngine::Cube{nodes7[7 * i + 5], (int)nodes7[7 * i], (int)nodes7[7 * i + 6]});
 	return 0;
 }
-int te_end(void*) { return 0; }
+int te_end(void* c) { static_cast<ToyEngine*>(c)->ended = true; return 0; }
 
-float run_world(int world, int rebalance, long long* donations)
+goicp_shard_engine_ops toy_ops(ToyEngine* e)
+{
+	goicp_shard_engine_ops eo{};
+	eo.ctx = e; eo.sse_threshold = 0.01f;
+	eo.begin = te_begin; eo.step = te_step; eo.pose = te_pose; eo.offer = te_offer; eo.queue_size = te_qsize;
+	eo.donate = te_donate; eo.receive = te_receive; eo.end = te_end;
+	return eo;
+}
+
+float run_world(int world, int rebalance, long long* donations, int stale = 0)
 {
 	std::vector<ToyEngine> eng((size_t)world);
 	std::vector<goicp_comm_ops> comm((size_t)world);
@@ -105,20 +124,75 @@ float run_world(int world, int rebalance, long long* donations)
 	std::vector<std::thread> th;
 	for (int r = 0; r < world; r++)
 		th.emplace_back([&, r] {
-			goicp_shard_engine_ops eo{};
-			eo.ctx = &eng[(size_t)r]; eo.sse_threshold = 0.01f;
-			eo.begin = te_begin; eo.step = te_step; eo.pose = te_pose; eo.offer = te_offer; eo.queue_size = te_qsize;
-			eo.donate = te_donate; eo.receive = te_receive; eo.end = te_end;
-			CHECK(goicp::run_sharded(&eo, &comm[(size_t)r], 3, rebalance, &st[(size_t)r]) == GOICP_OK);
+			goicp_shard_engine_ops eo = toy_ops(&eng[(size_t)r]);
+			goicp_shard_options o{3, rebalance, stale, 0};
+			CHECK(goicp::run_sharded(&eo, &comm[(size_t)r], &o, &st[(size_t)r]) == GOICP_OK);
 		});
 	for (auto& t : th) t.join();
 	for (int r = 0; r < world; r++) {
 		CHECK(eng[(size_t)r].best == eng[0].best);
 		CHECK(st[(size_t)r].exchanges == st[0].exchanges && st[(size_t)r].broadcasts == st[0].broadcasts);
+		CHECK(st[(size_t)r].failed_rank == -1 && st[(size_t)r].wait_ms >= 0.0);
 		goicp::thread_comm_destroy(&comm[(size_t)r]);
 	}
 	if (donations) *donations = st[0].donations;
 	return eng[0].best;
+}
+
+// one rank's callback fails: EVERY rank must come back with an error (its own status on the failing rank, GOICP_ERR_PEER
+// with failed_rank set on the others), promptly -- long before the 20 s deadline -- and with its registration ended
+void run_failure(int world, int bad_rank, int what, int at_step, int stale)
+{
+	std::vector<ToyEngine> eng((size_t)world);
+	eng[(size_t)bad_rank].fail_what = what; eng[(size_t)bad_rank].fail_at_step = at_step;
+	std::vector<goicp_comm_ops> comm((size_t)world);
+	CHECK(goicp::thread_comm_create(world, comm.data()) == GOICP_OK);
+	for (int r = 0; r < world; r++) CHECK(goicp::comm_set_timeout_ms(&comm[(size_t)r], 20000) == GOICP_OK);
+	std::vector<goicp_shard_stats> st((size_t)world);
+	std::vector<int> rc((size_t)world, 12345);
+	const auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> th;
+	for (int r = 0; r < world; r++)
+		th.emplace_back([&, r] {
+			goicp_shard_engine_ops eo = toy_ops(&eng[(size_t)r]);
+			goicp_shard_options o{3, 1, stale, 0};
+			rc[(size_t)r] = goicp::run_sharded(&eo, &comm[(size_t)r], &o, &st[(size_t)r]);
+		});
+	for (auto& t : th) t.join();
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	CHECK(secs < 10.0);
+	for (int r = 0; r < world; r++) {
+		if (r == bad_rank) CHECK(rc[(size_t)r] == (what == 2 ? GOICP_ERR_INTERNAL : GOICP_ERR_DEVICE));
+		else CHECK(rc[(size_t)r] == GOICP_ERR_PEER);
+		CHECK(st[(size_t)r].failed_rank == bad_rank);
+		CHECK(eng[(size_t)r].ended == (what != 4 || r != bad_rank));       // end() follows every successful begin()
+		goicp::thread_comm_destroy(&comm[(size_t)r]);
+	}
+}
+
+// a rank that never shows up: the others give up at the deadline with GOICP_ERR_TIMEOUT instead of hanging
+void run_missing_rank()
+{
+	const int world = 3;
+	std::vector<ToyEngine> eng((size_t)world);
+	std::vector<goicp_comm_ops> comm((size_t)world);
+	CHECK(goicp::thread_comm_create(world, comm.data()) == GOICP_OK);
+	for (int r = 0; r < world; r++) CHECK(goicp::comm_set_timeout_ms(&comm[(size_t)r], 300) == GOICP_OK);
+	std::vector<int> rc((size_t)world, 0);
+	const auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> th;
+	for (int r = 0; r < world - 1; r++)                                       // rank 2 is "dead"
+		th.emplace_back([&, r] {
+			goicp_shard_engine_ops eo = toy_ops(&eng[(size_t)r]);
+			goicp_shard_options o{3, 1, r == 0 ? 0 : 0, 0};
+			rc[(size_t)r] = goicp::run_sharded(&eo, &comm[(size_t)r], &o, nullptr);
+		});
+	for (auto& t : th) t.join();
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	CHECK(rc[0] == GOICP_ERR_TIMEOUT && rc[1] == GOICP_ERR_TIMEOUT);
+	CHECK(secs >= 0.25 && secs < 5.0);
+	CHECK(eng[0].ended && eng[1].ended);
+	for (int r = 0; r < world; r++) goicp::thread_comm_destroy(&comm[(size_t)r]);
 }
 
 }  // namespace
@@ -133,6 +207,18 @@ int main()
 		CHECK(std::fabs(b - single) <= 0.01f);
 	}
 	CHECK(std::fabs(run_world(4, 0, &don) - single) <= 0.01f && don == 0);
+	// one-step-stale exchange (helper thread): same optimum, collectives still matched on every rank
+	for (int w : {2, 4, 7}) CHECK(std::fabs(run_world(w, 1, &don, 1) - single) <= 0.01f);
+	CHECK(std::fabs(run_world(3, 0, &don, 1) - single) <= 0.01f && don == 0);
+	// failure is a collective decision; a lost rank is a timeout
+	for (int stale : {0, 1}) {
+		run_failure(2, 1, 1, 3, stale);      // step fails on rank 1 at its 3rd step
+		run_failure(4, 2, 1, 1, stale);      // ... on the very first step
+		run_failure(4, 0, 2, 0, stale);      // rank 0 cannot take the offered global best
+		run_failure(4, 3, 4, 0, stale);      // begin() fails
+	}
+	run_failure(4, 0, 3, 0, 0);              // whoever is asked to donate first cannot (rank 0 owns the largest queue at a tie)
+	run_missing_rank();
 	// ---- threaded k-d build ----
 	{
 		std::mt19937 rng(7);

@@ -1,23 +1,30 @@
 // RCCL communicator behind goicp_comm_ops: the exchanges of the sharded search (shard.cpp) as ncclAllReduce(MIN) /
 // ncclBroadcast over xGMI.  Payloads are 40-48 bytes (the donations 1.8 KB), so the collectives are latency-bound;
 // they run on a stream of their own -- never the engine's compute stream -- with one pinned staging block per
-// communicator (H2D, collective, D2H on that stream, one stream sync per exchange).
+// communicator (H2D, collective, D2H on that stream).  The host never blocks in hipStreamSynchronize: it polls
+// hipStreamQuery against the communicator's deadline (default 60 s), so a rank that died or left the protocol turns
+// into GOICP_ERR_TIMEOUT on the others instead of a hang; a communicator that missed a deadline is marked broken and,
+// when the library owns it, torn down with ncclCommAbort.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
-#include "../../include/goicp_mi355.h"
+#include "comm.hpp"
 
 namespace goicp {
 
 namespace {
 
 struct RcclComm {
+	CommHeader hdr{kCommMagic, 60000};     // first member (goicp_comm_set_timeout_ms)
+	bool broken = false;                   // a collective missed its deadline
 	ncclComm_t comm = nullptr;
 	bool owns = false;
 	int device = 0;
@@ -36,16 +43,40 @@ struct DevScope {
 	~DevScope() { if (prev >= 0 && prev != want) hipSetDevice(prev); }
 };
 
+// wait for the communicator's stream without ever blocking past the deadline: a short spin (the exchange takes 10-20 us),
+// then yields, then 50 us naps
+int wait_stream(RcclComm* c)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const auto deadline = t0 + std::chrono::milliseconds(c->hdr.timeout_ms);
+	for (long spins = 0;; spins++) {
+		const hipError_t q = hipStreamQuery(c->stream);
+		if (q == hipSuccess) return GOICP_OK;
+		if (q != hipErrorNotReady) { (void)hipGetLastError(); c->broken = true; return GOICP_ERR_DEVICE; }
+		(void)hipGetLastError();
+		ncclResult_t async = ncclSuccess;
+		if ((spins & 1023) == 1023 && (ncclCommGetAsyncError(c->comm, &async) != ncclSuccess || (async != ncclSuccess && async != ncclInProgress))) {
+			c->broken = true;
+			return GOICP_ERR_DEVICE;
+		}
+		const auto now = std::chrono::steady_clock::now();
+		if (now >= deadline) { c->broken = true; return GOICP_ERR_TIMEOUT; }
+		if (now - t0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+		else if (now - t0 > std::chrono::microseconds(200)) std::this_thread::yield();
+	}
+}
+
 int allreduce_min_u64(void* ctx, uint64_t* words, size_t n)
 {
 	RcclComm* c = static_cast<RcclComm*>(ctx);
+	if (c->broken) return GOICP_ERR_TIMEOUT;
 	if (n * sizeof(uint64_t) > c->cap) return GOICP_ERR_INVALID;
 	DevScope dev(c->device);
 	std::memcpy(c->h_buf, words, n * sizeof(uint64_t));
 	if (hipMemcpyAsync(c->d_buf, c->h_buf, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
 	if (ncclAllReduce(c->d_buf, c->d_buf, n, ncclUint64, ncclMin, c->comm, c->stream) != ncclSuccess) return GOICP_ERR_DEVICE;
 	if (hipMemcpyAsync(c->h_buf, c->d_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
-	if (hipStreamSynchronize(c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
+	if (const int rc = wait_stream(c)) return rc;
 	std::memcpy(words, c->h_buf, n * sizeof(uint64_t));
 	return GOICP_OK;
 }
@@ -53,13 +84,14 @@ int allreduce_min_u64(void* ctx, uint64_t* words, size_t n)
 int bcast(void* ctx, void* buf, size_t bytes, int32_t root)
 {
 	RcclComm* c = static_cast<RcclComm*>(ctx);
+	if (c->broken) return GOICP_ERR_TIMEOUT;
 	if (bytes > c->cap) return GOICP_ERR_INVALID;
 	DevScope dev(c->device);
 	std::memcpy(c->h_buf, buf, bytes);
 	if (hipMemcpyAsync(c->d_buf, c->h_buf, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
 	if (ncclBroadcast(c->d_buf, c->d_buf, bytes, ncclUint8, root, c->comm, c->stream) != ncclSuccess) return GOICP_ERR_DEVICE;
 	if (hipMemcpyAsync(c->h_buf, c->d_buf, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
-	if (hipStreamSynchronize(c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
+	if (const int rc = wait_stream(c)) return rc;
 	std::memcpy(buf, c->h_buf, bytes);
 	return GOICP_OK;
 }
@@ -76,6 +108,7 @@ int finish(RcclComm* c, int32_t rank, int32_t world, goicp_comm_ops* out)
 		return GOICP_ERR_DEVICE;
 	}
 	c->cap = kStageBytes;
+	c->hdr.timeout_ms = comm_default_timeout_ms();
 	out->ctx = c; out->rank = rank; out->world = world;
 	out->allreduce_min_u64 = &allreduce_min_u64;
 	out->bcast = &bcast;
@@ -121,10 +154,20 @@ int rccl_comm_destroy(goicp_comm_ops* comm)
 	RcclComm* c = static_cast<RcclComm*>(comm->ctx);
 	{
 		DevScope dev(c->device);
-		hipStreamSynchronize(c->stream);
-		hipStreamDestroy(c->stream);
-		hipFree(c->d_buf); hipHostFree(c->h_buf);
-		if (c->owns && c->comm) ncclCommDestroy(c->comm);
+		if (c->broken) {
+			// a collective is stuck on the stream: abort the communicator first (its kernels then leave), never wait on it;
+			// a wrapped communicator stays the caller's to abort, its stream and staging blocks are left alone (leaked)
+			if (c->owns && c->comm) {
+				ncclCommAbort(c->comm);
+				hipStreamDestroy(c->stream);
+				hipFree(c->d_buf); hipHostFree(c->h_buf);
+			}
+		} else {
+			hipStreamSynchronize(c->stream);
+			hipStreamDestroy(c->stream);
+			hipFree(c->d_buf); hipHostFree(c->h_buf);
+			if (c->owns && c->comm) ncclCommDestroy(c->comm);
+		}
 	}
 	delete c;
 	comm->ctx = nullptr;

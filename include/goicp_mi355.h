@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GOICP_ABI_VERSION 2
+#define GOICP_ABI_VERSION 3
 
 typedef enum goicp_status {
 	GOICP_OK = 0,
@@ -35,7 +35,10 @@ typedef enum goicp_status {
 	GOICP_ERR_CONFIG = -3,     /* TOML parse error / missing info.description (src/common.cpp:28-40) */
 	GOICP_ERR_NO_DEVICE = -4,  /* no HIP device: the product never computes on the CPU */
 	GOICP_ERR_DEVICE = -5,     /* HIP runtime failure (reference: exit(EXIT_FAILURE), src/kernel.cu:29-38) */
-	GOICP_ERR_INTERNAL = -6
+	GOICP_ERR_INTERNAL = -6,
+	GOICP_ERR_TIMEOUT = -7,    /* a collective of the sharded search did not complete within the communicator's deadline: the
+	                              process must exit non-zero (a rank is lost); never re-execute */
+	GOICP_ERR_PEER = -8        /* another rank of the sharded search reported a failure (goicp_shard_stats.failed_rank) */
 } goicp_status;
 
 const char* goicp_last_error(void);
@@ -267,10 +270,14 @@ int goicp_offer_best(goicp_handle h, float sse, const float R[9], const float t[
 int goicp_register_end(goicp_handle h);
 
 /* ---- the sharded registration inside the library (csrc/shard.cpp, csrc/rccl_comm.cpp) ------------------------------
- * One call per rank drives the whole protocol: step the local search, ONE all-reduce(MIN) of five packed 64-bit words
- * per step ({best SSE, rank}, frontier lower bound, early-exit / active / idle flags), a 48-byte broadcast of the winner's
- * R|t only when the global best moved, global termination, and -- when a rank runs dry -- rebalancing (queue sizes
- * gathered, every second cube of the largest queue broadcast to the idle rank).
+ * One call per rank drives the whole protocol: step the local search, ONE all-reduce(MIN) of six packed 64-bit words
+ * per step ({best SSE, rank}, frontier lower bound, early-exit / active / idle flags, failure word), a 48-byte broadcast
+ * of the winner's R|t only when the global best moved, global termination, and -- when a rank runs dry -- rebalancing
+ * (queue sizes gathered, every second cube of the largest queue broadcast to the idle rank).
+ * Failure is a collective decision: a rank whose engine callback fails keeps taking part in the exchange, every rank
+ * leaves the loop in the same iteration, ends its registration and returns an error (its own status, or GOICP_ERR_PEER
+ * with goicp_shard_stats.failed_rank set).  A collective that misses the communicator's deadline returns
+ * GOICP_ERR_TIMEOUT on the rank that waited.
  * The communicator is a callback table, so the protocol also runs (and is tested) without RCCL. */
 typedef struct goicp_comm_ops {
 	void* ctx;
@@ -282,8 +289,20 @@ typedef struct goicp_comm_ops {
 } goicp_comm_ops;
 typedef struct goicp_shard_stats {
 	int64_t steps, exchanges, broadcasts, donations, donated_cubes;
+	int64_t steps_idle;   /* steps in which this rank had nothing left to expand while the search went on */
+	double wait_ms;       /* host time this rank spent blocked in collectives (waiting for the slowest rank) */
+	double step_ms;       /* host time inside the engine's step() */
 	float best_sse;
+	int32_t failed_rank;  /* -1, or the rank whose failure ended the run */
 } goicp_shard_stats;
+typedef struct goicp_shard_options {
+	int32_t rot_pops_per_step;  /* rotation parents per step (>= 1) */
+	int32_t rebalance;          /* 1: idle ranks receive cubes from the largest queue */
+	int32_t stale_exchange;     /* 0: the exchange of a step is consumed before the next step (bulk-synchronous);
+	                               1: it runs on a helper thread while the next step is evaluated and is consumed after it --
+	                               a rank waits only for ranks more than one step behind */
+	int32_t reserved;
+} goicp_shard_options;
 /* the engine side of the protocol as a callback table (goicp_register_sharded fills it for a real engine; tests
  * supply a CPU stand-in).  nodes7: 7 floats per rotation cube {corner x,y,z, width, ub, lb, level}. */
 typedef struct goicp_shard_engine_ops {
@@ -303,6 +322,15 @@ int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops
 /* the same for an engine handle (blocking; one call per rank, each rank with its own engine on its own GPU) */
 int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
                            goicp_shard_stats* stats);
+/* both with the full option set */
+void goicp_shard_options_default(goicp_shard_options* out);
+int goicp_run_sharded_opt(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, const goicp_shard_options* opt,
+                          goicp_shard_stats* stats);
+int goicp_register_sharded_opt(goicp_handle h, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats);
+/* deadline of every single collective of a communicator made by this library (thread or RCCL); default: the
+ * environment's GOICP_COMM_TIMEOUT_MS, else 60 000 ms.  A collective that misses it returns GOICP_ERR_TIMEOUT and leaves
+ * the communicator unusable (destroy it; an RCCL communicator the library owns is aborted with ncclCommAbort). */
+int goicp_comm_set_timeout_ms(goicp_comm_ops* comm, int32_t timeout_ms);
 /* in-process communicator: `world` host threads of ONE process, rank r calling with out[r] (tests; rehearsing the
  * N-rank path with N engines on one GPU).  Destroy every element. */
 int goicp_thread_comm_create(int32_t world, goicp_comm_ops* out /* [world] */);

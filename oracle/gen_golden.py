@@ -76,9 +76,53 @@ def bunny_icp_to_f32(dst_target, dst_source):
     return out
 
 
+def f32_to_txt(a, dst):
+    """A float32 cloud as the reference's .txt format (`N` then N x `x y z`, src/common.cpp:148-203); %.9g round-trips a
+    float32 exactly through the harness's "%f" parse."""
+    a = np.asarray(a, dtype=np.float32)
+    with open(dst, "w") as f:
+        f.write("%d\n" % len(a))
+        for x, y, z in a:
+            f.write("%.9g %.9g %.9g\n" % (x, y, z))
+
+
+def sub_configs(h, tmp):
+    """BASELINE configs[2] (skull) and configs[3] (spanner) pinned to the reference: the real GoICP::Register
+    (src/goicp/jly_goicp.cpp:569-585) on the full targets (the DT is built over all their points) and strided sources, so
+    that the reference's CPU run takes minutes instead of days:
+      spanner_sub  target = spanner_target.f32 (noisy_flipped_model_spanner.ply x 0.02, 150 000 points), source = every 50th
+                   point of spanner_source.f32 (rotated_model_spanner.ply x 0.02), mse 1e-4 (test/spanner_goicp.toml:10-20)
+      skull_sub    target = skull_scan.f32 (data_skull.ply x 0.01, 98 359 points), source = every 10th point of the seeded
+                   30 % subsample under the known motion (tests/conftest.py:skull_problem), mse 1e-3 (test/skull_goicp.toml:10-20)
+    plus the reference's InnerBnB (single expansions + full searches) on the spanner DT -> inner_bnb_spanner.json."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cloud, skull_problem
+    os.makedirs(tmp, exist_ok=True)
+    sp_t, sp_s = os.path.join(tmp, "spanner_target.txt"), os.path.join(tmp, "spanner_source.txt")
+    f32_to_txt(cloud("spanner_target"), sp_t)
+    f32_to_txt(cloud("spanner_source"), sp_s)
+    target, source, _, _ = skull_problem()
+    sk_t, sk_s = os.path.join(tmp, "skull_target.txt"), os.path.join(tmp, "skull_source.txt")
+    f32_to_txt(target, sk_t)
+    f32_to_txt(source, sk_s)
+    units_dir = os.path.join(tmp, "units_spanner")
+    os.makedirs(units_dir, exist_ok=True)
+    procs = [
+        subprocess.Popen([h, "e2e", OUT, "spanner_sub", sp_t, sp_s, "1e-4", "50"], stdout=subprocess.DEVNULL),
+        subprocess.Popen([h, "e2e", OUT, "skull_sub", sk_t, sk_s, "1e-3", "10"], stdout=subprocess.DEVNULL),
+        subprocess.Popen([h, "units", units_dir, sp_t, sp_s, "50"], stdout=subprocess.DEVNULL),
+    ]
+    rc = [p.wait() for p in procs]
+    if any(rc):
+        sys.exit("harness failed: %r" % rc)
+    os.replace(os.path.join(units_dir, "inner_bnb.json"), os.path.join(OUT, "inner_bnb_spanner.json"))
+    print("sub-config fixtures written to", OUT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--sub-configs", action="store_true", help="only the strided skull / spanner fixtures (configs[2], [3])")
     ap.add_argument("--clouds-only", action="store_true", help="only (re)write the input-cloud blobs")
     args = ap.parse_args()
     if not os.path.isdir(REF):
@@ -86,6 +130,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     subprocess.check_call(["make", "-C", HERE, "ref"])
     h = os.path.join(HERE, "_ref", "ref_harness")
+    if args.sub_configs:
+        return sub_configs(h, "/tmp/goicp_gen_golden")
     mb, db = os.path.join(BUNNY, "model_bunny.txt"), os.path.join(BUNNY, "data_bunny.txt")
     mr, dr = os.path.join(BUNNY, "model_rand.txt"), os.path.join(BUNNY, "data_rand.txt")
     for name, src in (("model_bunny", mb), ("data_bunny", db), ("model_rand", mr), ("data_rand", dr)):

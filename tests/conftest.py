@@ -40,6 +40,22 @@ def cloud(name, stride=1):
     return np.ascontiguousarray(a[::stride])
 
 
+def skull_problem():
+    """BASELINE configs[2] as SURVEY 8d builds it: target = the reference's data_skull.ply x 0.01 (98 359 points, committed
+    blob), source = a seeded 30 % subsample of it under the rigid motion Rz(2.1) Ry(-0.7) Rx(1.3), t = (0.15, -0.10, 0.05),
+    + N(0, 1e-3) noise.  Returns (target, source, Rgt, tgt) with target ~= Rgt source + tgt.  Shared by the GPU test and by
+    oracle/gen_golden.py (which feeds every 10th source point to the reference's own GoICP::Register)."""
+    target = cloud("skull_scan")
+    rng = np.random.default_rng(1234)
+    sub = target[rng.random(len(target)) < 0.3].astype(np.float64)
+    cx, sx, cy, sy, cz, sz = np.cos(1.3), np.sin(1.3), np.cos(-0.7), np.sin(-0.7), np.cos(2.1), np.sin(2.1)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    Rgt, tgt = Rz @ Ry @ Rx, np.array([0.15, -0.10, 0.05])
+    source = ((sub - tgt) @ Rgt + rng.normal(scale=1e-3, size=sub.shape)).astype(np.float32)   # target ~= Rgt source + tgt
+    return target, source, Rgt, tgt
+
+
 def rot_angle(Ra, Rb):
     """Geodesic angle between two rotations, from the chord ||Ra-Rb||_F = 2*sqrt(2)*sin(theta/2)
     (well conditioned near 0, unlike arccos of the trace)."""

@@ -338,7 +338,7 @@ def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):
 # ----------------------------------------------------------------------------------------------
 # end to end (FastGoICP::run == GoICP::Register)
 # ----------------------------------------------------------------------------------------------
-def _e2e(pkg, tag, model, data, strict=True, **params):
+def _e2e(pkg, tag, model, data, strict=True, wide_tol=(3e-2, 1e-2), **params):
     """strict (reference visit order): R within 2e-3 rad, t within 2e-3, SSE within 2 %.
     Widened search (speculative batches): Go-ICP's guarantee is the error, not the pose -- the early
     exit (jly_goicp.cpp:527) accepts the first ICP optimum below SSEThresh, and a different visit order
@@ -350,13 +350,15 @@ def _e2e(pkg, tag, model, data, strict=True, **params):
     assert eng.finished
     sse = eng.get_best_error()
     ang, dt = rot_angle(eng.optR, np.array(g["R"])), np.linalg.norm(eng.optT - np.array(g["t"]))
+    slack = 1e-3 * g["sse_threshold"]          # the strided skull / spanner optima score an SSE of (nearly) 0
     if strict:
-        assert ang <= 2e-3 and dt <= 2e-3
-        assert abs(sse - g["sse"]) <= 0.02 * g["sse"]
+        assert ang <= 2e-3 and dt <= 2e-3, (ang, dt)
+        assert abs(sse - g["sse"]) <= 0.02 * g["sse"] + slack
     else:
-        assert ang <= 3e-2 and dt <= 1e-2
-        assert sse <= 1.02 * g["sse"]
+        assert ang <= wide_tol[0] and dt <= wide_tol[1], (ang, dt)
+        assert sse <= 1.02 * g["sse"] + slack
     assert sse < g["sse_threshold"]
+    print("e2e %s strict=%d: rot_error_rad %.3e trans_error %.3e sse %.6g (reference %.6g)" % (tag, strict, ang, dt, sse, g["sse"]))
     return eng, g
 
 
@@ -407,15 +409,97 @@ def test_e2e_bunny_full_reference_order(pkg, bunny_model, bunny_data):
     assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"]
 
 
+def _e2e_counts(eng, g):
+    c = eng.counters
+    assert abs(c.rot_pops - g["rNodeCount"]) <= max(1, 0.02 * g["rNodeCount"]), (c.rot_pops, g["rNodeCount"])
+    assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"], (c.trans_pops, g["tNodeCount"])
+
+
+def test_e2e_skull_sub_reference_order(pkg):
+    """BASELINE configs[2] pinned to the reference: the real GoICP::Register (src/goicp/jly_goicp.cpp:569-585) on the
+    skull scan (98 359-point target, the DT over all of it) and every 10th point of the known-motion source
+    (tests/golden/e2e_skull_sub.json, oracle/gen_golden.py --sub-configs; mse 1e-3, test/skull_goicp.toml:10-20).
+    Reference visit order: pose <= 2e-3 rad / 2e-3, SSE, node counts within 2 %."""
+    from conftest import skull_problem
+    target, source, _, _ = skull_problem()
+    eng, g = _e2e(pkg, "skull_sub", target, np.ascontiguousarray(source[::10]), trans_batch=1, wide_children=0)
+    _e2e_counts(eng, g)
+    eng.registration.close()
+
+
+def test_e2e_skull_sub_wide(pkg):
+    from conftest import skull_problem
+    target, source, _, _ = skull_problem()
+    eng, _ = _e2e(pkg, "skull_sub", target, np.ascontiguousarray(source[::10]), strict=False)
+    eng.registration.close()
+
+
+def test_e2e_spanner_sub_reference_order(pkg):
+    """BASELINE configs[3] pinned to the reference: GoICP::Register on the noisy spanner (150 000-point target) and every
+    50th point of the rotated model, mse 1e-4 (test/spanner_goicp.toml:10-20; tests/golden/e2e_spanner_sub.json: 92
+    rotation / 16 918 translation nodes, SSE 0 -- every strided source point ends in a seeded voxel).  Reference visit
+    order: pose <= 2e-3 rad / 2e-3, SSE, node counts within 2 %."""
+    eng, g = _e2e(pkg, "spanner_sub", cloud("spanner_target"), cloud("spanner_source", 50), trans_batch=1, wide_children=0)
+    _e2e_counts(eng, g)
+    eng.registration.close()
+
+
+def test_e2e_spanner_sub_wide(pkg):
+    """The same through the default (widened, device-queue) search, and sharded over 2 thread ranks: SSE <= reference."""
+    from cuda_go_icp_amd import sharded
+    target, source = cloud("spanner_target"), cloud("spanner_source", 50)
+    eng, g = _e2e(pkg, "spanner_sub", target, source, strict=False)
+    eng.registration.close()
+    engines = [pkg.FastGoICP(target, source, g["mse_threshold"]) for _ in range(2)]
+    sharded.run_thread_ranks(engines, rot_pops_per_step=8)
+    for e in engines:
+        assert float(e.get_best_error()) <= 1.02 * g["sse"] + 1e-3 * g["sse_threshold"]
+        assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2 and np.linalg.norm(e.optT - np.array(g["t"])) <= 1e-2
+        e.registration.close()
+
+
+def test_golden_inner_bnb_spanner(pkg):
+    """The reference's InnerBnB on the spanner DT (tests/golden/inner_bnb_spanner.json): single expansions rel 1e-4 +
+    arg-min child, full searches in the reference visit order value rel 1e-3, pops within 1 %."""
+    g = golden("inner_bnb_spanner")
+    reg = pkg.Registration(cloud("spanner_target"), cloud("spanner_source", 50), 1e-3, trans_batch=1, wide_children=0)
+    for case in g["cases"]:
+        R = np.array(case["R"], np.float32)
+        for s in case["single"]:
+            px, py, pz, pw = map(np.float32, s["parent"])
+            w = pw / np.float32(2)
+            kids = []
+            for j in range(8):
+                cx = px + np.float32(j & 1) * w; cy = py + np.float32(j >> 1 & 1) * w; cz = pz + np.float32(j >> 2 & 1) * w
+                kids.append([cx + w / np.float32(2), cy + w / np.float32(2), cz + w / np.float32(2), w, cx, cy, cz])
+            kids = np.array(kids, np.float32)
+            ub, _ = reg.eval_bounds(R, kids[:, :4], s["level"])
+            j = int(np.argmin(ub))
+            assert abs(ub[j] - s["min_ub"]) <= 1e-4 * max(s["min_ub"], 1e-3)
+            if np.sum(np.abs(ub - ub[j]) <= 2e-5 * max(ub[j], 1e-3)) == 1:
+                assert np.array_equal(kids[j, 4:7], np.array(s["best"][:3], np.float32))
+        for s in case["full"]:
+            v, best, cnt = reg.inner_bnb(R, s["level"], s["incumbent"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(cnt.trans_pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+    reg.close()
+
+
 def test_sharded_two_ranks_same_optimum(pkg, bunny_model, bunny_data10):
-    """Rotation cubes dealt to 2 ranks (both on this GPU, stepped alternately) with a min-exchange of
-    the best error between steps reach the single-rank optimum (SURVEY 8e invariant)."""
+    """Rotation cubes dealt to 2 ranks (two engines on this GPU, one host thread each, the LIBRARY's protocol over its
+    in-process communicator), bulk-synchronous and with the one-step-stale exchange: both reach the single-rank
+    optimum (SURVEY 8e invariant) and end with the same global best."""
     from cuda_go_icp_amd import sharded
     g = golden("e2e_bunny10")
-    engines = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"]) for _ in range(2)]
-    sse, R, t, stats = sharded.run_local_ranks(engines, rot_pops_per_step=4)
-    assert rot_angle(R, np.array(g["R"])) <= 3e-2 and np.linalg.norm(t - np.array(g["t"])) <= 1e-2
-    assert sse <= 1.02 * g["sse"] and sse < g["sse_threshold"]
+    for stale in (False, True):
+        engines = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"]) for _ in range(2)]
+        stats = sharded.run_thread_ranks(engines, rot_pops_per_step=4, stale=stale)
+        sse = [float(e.get_best_error()) for e in engines]
+        assert sse[0] == sse[1] and all(s["status"] == 0 for s in stats)
+        for e in engines:
+            assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2 and np.linalg.norm(e.optT - np.array(g["t"])) <= 1e-2
+            assert sse[0] <= 1.02 * g["sse"] and sse[0] < g["sse_threshold"]
+            e.registration.close()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -466,20 +550,15 @@ def test_fullsize_registration_recovers_ground_truth(pkg, s1):
 
 
 def test_skull_scan_known_motion(pkg, oracle_mod):
-    """BASELINE configs[2] (skull_goicp.toml: larger cloud, k-d NN path stressed).  The config's target
+    """BASELINE configs[2] (skull_goicp.toml: larger cloud, k-d NN path stressed), full size.  The config's target
     model_skull.ply is missing from the reference checkout, so -- as SURVEY 8d prescribes -- the problem is
     built from the scan the reference does hold (data_skull.ply, 98 359 points, resize 0.01; committed
     fixture): target = the scan, source = a seeded 30 % subsample moved by a known rigid motion + N(0, 1e-3)
-    noise.  The motion must be recovered.  Parity with the reference is unpinned for this case (its CPU
-    run takes hours); the bar is the ground truth."""
-    target = cloud("skull_scan")
-    rng = np.random.default_rng(1234)
-    sub = target[rng.random(len(target)) < 0.3].astype(np.float64)
-    cx, sx, cy, sy, cz, sz = np.cos(1.3), np.sin(1.3), np.cos(-0.7), np.sin(-0.7), np.cos(2.1), np.sin(2.1)
-    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-    Rgt, tgt = Rz @ Ry @ Rx, np.array([0.15, -0.10, 0.05])
-    source = ((sub - tgt) @ Rgt + rng.normal(scale=1e-3, size=sub.shape)).astype(np.float32)   # target ~= Rgt source + tgt
+    noise (conftest.skull_problem).  The motion must be recovered.  Parity with the reference on this problem is pinned
+    by test_e2e_skull_sub_* (the reference's own GoICP::Register on every 10th source point); at full size the bar is the
+    ground truth."""
+    from conftest import skull_problem
+    target, source, Rgt, tgt = skull_problem()
     eng = pkg.FastGoICP(target, source, 1e-3)
     eng.run()
     assert eng.finished and eng.get_best_error() < eng.sse_threshold
@@ -788,9 +867,10 @@ def test_spanner_noisy(pkg, oracle_mod):
     """BASELINE configs[3], test/spanner_goicp.toml:10-20: target noisy_flipped_model_spanner.ply (150 000 points,
     sigma 0.5 * resize 0.02 = 0.01 noise per axis), resize 0.02, mse_threshold 1e-4 -> SSEThresh 15.  The config's source
     model_spanner.ply is missing from the reference checkout (.MISSING_LARGE_BLOBS:4); SURVEY 8d's substitute
-    rotated_model_spanner.ply (the model under a random rotation, 150 000 points) is used -- parity with the reference is
-    therefore UNPINNED for this case (its CPU run would also take days); the bar is the ground truth, which the two
-    files define through their point-by-point correspondence.  Checked: single engine below SSEThresh at the true pose;
+    rotated_model_spanner.ply (the model under a random rotation, 150 000 points) is used.  Parity with the reference on
+    this pair is pinned by test_e2e_spanner_sub_* and test_golden_inner_bnb_spanner (the reference's own GoICP::Register /
+    InnerBnB on the full target and every 50th source point); at full size (days of reference CPU time) the bar is the
+    ground truth, which the two files define through their point-by-point correspondence.  Checked: single engine below SSEThresh at the true pose;
     2 and 4 sharded engines reach the same optimum (SURVEY 8e invariant); exact NN on this hierarchy; cube bounds
     against the oracle on a 1/10 subsample."""
     from cuda_go_icp_amd import sharded
@@ -814,12 +894,15 @@ def test_spanner_noisy(pkg, oracle_mod):
     bi, bd = oracle_mod.nn_brute(target, q)
     assert np.array_equal(d2, bd) and np.array_equal(idx, bi)
     eng.registration.close()
-    # sharded: the rotation cubes dealt to 2 / 4 engines, min-exchange of the best error between steps
-    for world in (2, 4):
+    # sharded: the rotation cubes dealt to 2 / 4 engines on this GPU, the library's protocol (csrc/shard.cpp) over its
+    # in-process communicator, one host thread per rank
+    for world, stale in ((2, False), (4, False), (4, True)):
         engines = [pkg.FastGoICP(target, source, 1e-4) for _ in range(world)]
-        sse, R, t, _ = sharded.run_local_ranks(engines, rot_pops_per_step=8)
-        assert sse < engines[0].sse_threshold and abs(sse - sse1) <= 0.05 * sse1
-        assert rot_angle(R, Rgt) <= 1e-2 and np.linalg.norm(t - tgt) <= 5e-3
+        stats = sharded.run_thread_ranks(engines, rot_pops_per_step=8, stale=stale)
+        best = [float(e.get_best_error()) for e in engines]
+        assert max(best) == min(best) and all(s["status"] == 0 for s in stats)
+        assert best[0] < engines[0].sse_threshold and abs(best[0] - sse1) <= 0.05 * sse1
+        assert all(rot_angle(e.optR, Rgt) <= 1e-2 and np.linalg.norm(e.optT - tgt) <= 5e-3 for e in engines)
         for e in engines:
             e.registration.close()
     # cube bounds vs the oracle on every 10th source point (same DT: V = 300 over the noisy target)
@@ -924,6 +1007,45 @@ def test_search_ranges_applied(pkg, bunny_model, bunny_data10):
     assert shallow.finished and shallow.counters.rot_pops <= 1 + 8 + 64
     for e in (base, full, box, away, shallow):
         e.registration.close()
+
+
+def test_search_range_with_a_degenerate_axis(pkg, bunny_model):
+    """A search range of zero width on an axis (rotation about z only; translation with z fixed) must not cull the whole
+    search: centred, the fixed value would sit exactly on the first split plane and the strict box test would drop both
+    children (the search would end after one pop with the start pose).  Problem: the bunny model against a copy of itself
+    rotated by 0.7 rad about z and shifted in the xy-plane; ICP refinement off, so only the BnB can find the pose."""
+    rng = np.random.default_rng(5)
+    sub = bunny_model[rng.choice(len(bunny_model), 3000, replace=False)].astype(np.float64)
+    c, s_ = np.cos(0.7), np.sin(0.7)
+    Rgt, tgt = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]), np.array([0.10, -0.05, 0.0])
+    source = ((sub - tgt) @ Rgt).astype(np.float32)                      # target = Rgt source + tgt
+    for dq in (1, 0):                                                    # device queues and host queues
+        eng = pkg.FastGoICP(bunny_model, source, 1e-3, icp_max_iter=0, device_queues=dq,
+                            use_rot_range=1, rot_min=[0, 0, -180], rot_max=[0, 0, 180],
+                            use_trans_range=1, trans_min=[-0.5, -0.5, 0], trans_max=[0.5, 0.5, 0])
+        eng.run()
+        assert eng.finished and eng.counters.rot_pops > 1 and eng.counters.cubes > 64
+        assert eng.get_best_error() < eng.sse_threshold
+        assert rot_angle(eng.optR, Rgt) <= 0.05 and np.linalg.norm(eng.optT - tgt) <= 0.03
+        assert abs(eng.optR[2, 2] - 1) < 1e-6 and abs(eng.optT[2]) < 1e-6       # the pose stays on the configured plane
+        eng.registration.close()
+    # a point range: one cube, evaluated and done
+    one = pkg.FastGoICP(bunny_model, source, 1e-3, icp_max_iter=0, use_rot_range=1, rot_min=[0, 0, 40], rot_max=[0, 0, 40],
+                        use_trans_range=1, trans_min=[0.1, -0.05, 0], trans_max=[0.1, -0.05, 0])
+    one.run()
+    assert one.finished
+    one.registration.close()
+
+
+def test_flow_with_a_wide_rotation_batch(pkg, bunny_model, bunny_data10):
+    """flow > 0 with rot_batch beyond the flow mode's 2 048 search slots / 16 used to spin forever (nothing could be
+    admitted even with every slot free): the admission width is clamped, the registration ends with the usual optimum."""
+    g = golden("e2e_bunny10")
+    eng = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], flow=8, rot_batch=256)
+    eng.run()
+    assert eng.finished and eng.get_best_error() <= 1.02 * g["sse"] and eng.get_best_error() < g["sse_threshold"]
+    assert rot_angle(eng.optR, np.array(g["R"])) <= 3e-2
+    eng.registration.close()
 
 
 def test_progress_callback_and_device(pkg, bunny_model, bunny_data10):
@@ -1123,7 +1245,9 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
     assert abs(float(one.sse_threshold) - g["mse_threshold"] * int(len(bunny_data10) * np.float32(0.9))) < 1e-4
     one.run()
     pair = [pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], trim_fraction=0.1) for _ in range(2)]
-    sse, R, t, _ = sharded.run_local_ranks(pair, rot_pops_per_step=4)
+    sharded.run_thread_ranks(pair, rot_pops_per_step=4)
+    sse, R = float(pair[0].get_best_error()), pair[0].optR
+    assert sse == float(pair[1].get_best_error())
     assert sse < pair[0].sse_threshold and abs(sse - float(one.get_best_error())) <= float(one.sse_threshold)
     assert rot_angle(R, one.optR) <= 5e-2
     for e in [one] + pair:

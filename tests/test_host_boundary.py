@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(pkg):
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in the header but not exported" % name
     assert declared == set(binding.SYMBOLS), (declared ^ set(binding.SYMBOLS))
-    assert lib.goicp_abi_version() == 2
+    assert lib.goicp_abi_version() == 3
 
 
 def test_struct_sizes_match_abi(pkg):
@@ -80,6 +80,28 @@ def test_config_parse_defaults_and_clamps(pkg, tmp_path):
     assert c.viz.theta == 0.5 and c.viz.phi == pytest.approx(0.4) and c.viz.spin_after_finish
     assert c.rotation.xmin == -90 and c.rotation.xmax == 180 and c.rotation.search_depth == 7
     assert c.description == "Register data # not a comment"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/test"), reason="the reference checkout only exists in the build container")
+def test_reference_configs_parse(pkg):
+    """The reference's five configs (test/*.toml, e.g. test/skull_goicp.toml:16-41) go through goicp_config_load unchanged and
+    give the values of the committed expectation table (tests/golden/reference_configs.json, written from reading the files):
+    [io] paths, [params] mode / trim / subsample / mse_threshold / resize, [visualization], and the [params.rotation] /
+    [params.translation] / search_depth keys the reference declares but never parses (src/common.h:157-169)."""
+    import json
+    table = json.load(open(os.path.join(GOLDEN, "reference_configs.json")))
+    assert sorted(table) == sorted(n for n in os.listdir("/root/reference/test") if n.endswith(".toml"))
+    for name, want in table.items():
+        c = pkg.Config(os.path.join("/root/reference/test", name))
+        assert (c.mode, bool(c.trim), c.description) == (want["mode"], want["trim"], want["description"]), name
+        for k in ("subsample", "mse_threshold", "resize"):
+            assert getattr(c, k) == pytest.approx(want[k], rel=1e-6), (name, k)
+        assert (c.io.target, c.io.source, c.io.output, c.io.visualization) == (want["target"], want["source"], want["output"], want["visualization"])
+        assert c.viz.theta == pytest.approx(want["theta"], rel=1e-6) and c.viz.phi == pytest.approx(want["phi"], rel=1e-6)
+        assert bool(c.viz.spin_after_finish) == want["spin_after_finish"]
+        for sect, key in ((c.rotation, "rotation"), (c.translation, "translation")):
+            assert [sect.xmin, sect.xmax, sect.ymin, sect.ymax, sect.zmin, sect.zmax, sect.search_depth] == want[key], (name, key)
+            assert bool(sect.present) == want[key + "_present"], (name, key)
 
 
 def test_config_errors(pkg, tmp_path):

@@ -162,6 +162,66 @@ def test_e2e_bunny10(oracle_mod, bunny_model, bunny_data10):
     assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]
 
 
+def _check_e2e_sub(oracle_mod, tag, model, data):
+    """Strided BASELINE configs[2] / [3] (oracle/gen_golden.py --sub-configs): the optimum's DT-scored SSE can be exactly
+    0 here (every strided source point lands in a seeded voxel of the dense target), so SSE is compared absolutely
+    against SSEThresh rather than relatively."""
+    g = golden("e2e_" + tag)
+    assert len(model) == g["Nm"] and len(data) == g["Nd"]
+    dt = oracle_mod.DistanceTransform(model, 300, 2.0)
+    assert dt.scale == g["dt_scale"] and dt.origin == (g["dt_xmin"], g["dt_ymin"], g["dt_zmin"])
+    r = oracle_mod.register(dt, model, data, g["mse_threshold"])
+    assert rot_angle(r["R"], np.array(g["R"]).reshape(3, 3)) <= 2e-3
+    assert np.linalg.norm(r["t"] - np.array(g["t"])) <= 2e-3
+    assert abs(r["sse"] - g["sse"]) <= 0.02 * g["sse"] + 1e-3 * g["sse_threshold"]
+    assert r["sse"] < g["sse_threshold"]
+    assert abs(r["rot_pops"] - g["rNodeCount"]) <= max(1, 0.02 * g["rNodeCount"])
+    assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.02 * g["tNodeCount"]
+
+
+def test_e2e_skull_sub(oracle_mod):
+    """BASELINE configs[2]: the reference's own GoICP::Register on the skull scan (98 359-point target) and every 10th
+    point of the seeded known-motion source (conftest.skull_problem)."""
+    from conftest import skull_problem
+    target, source, Rgt, tgt = skull_problem()
+    _check_e2e_sub(oracle_mod, "skull_sub", target, np.ascontiguousarray(source[::10]))
+    g = golden("e2e_skull_sub")
+    assert rot_angle(np.array(g["R"]).reshape(3, 3), Rgt) <= 5e-3 and np.linalg.norm(np.array(g["t"]) - tgt) <= 5e-3   # the reference recovers the motion
+
+
+@pytest.mark.slow
+def test_e2e_spanner_sub(oracle_mod):
+    """BASELINE configs[3]: the reference's own GoICP::Register on the noisy spanner (150 000-point target) and every
+    50th point of the rotated model, mse 1e-4 (92 rotation / 16 918 translation nodes)."""
+    _check_e2e_sub(oracle_mod, "spanner_sub", cloud("spanner_target"), cloud("spanner_source", 50))
+
+
+def test_inner_bnb_spanner(oracle_mod):
+    """The reference's InnerBnB on the spanner DT (V = 300 over the 150 000 noisy target points), every 50th source
+    point: single expansions (min ub + arg-min child) and full searches, as test_inner_bnb_* do on the bunny."""
+    g = golden("inner_bnb_spanner")
+    data = cloud("spanner_source", 50)
+    assert len(data) == g["Nd"]
+    dt = oracle_mod.DistanceTransform(cloud("spanner_target"), 300, 2.0)
+    _, rho = oracle_mod.rot_radii(data)
+    n = 0
+    for case in g["cases"]:
+        prot = oracle_mod.rotate(np.array(case["R"], dtype=np.float32).reshape(3, 3), data)
+        for s in case["single"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, cubes = oracle_mod.inner_bnb(dt, prot, r, 1e10, 1e9, root=s["parent"])
+            assert pops == s["pops"] and cubes == 8
+            assert abs(v - s["min_ub"]) <= 1e-4 * max(s["min_ub"], 1e-3)
+            assert np.array_equal(best, np.array(s["best"], dtype=np.float32))
+            n += 1
+        for s in case["full"]:
+            r = rho[s["level"]] if s["level"] >= 0 else None
+            v, best, pops, _ = oracle_mod.inner_bnb(dt, prot, r, s["incumbent"], g["sse_threshold"])
+            assert abs(v - s["value"]) <= 1e-3 * max(s["value"], 1e-3)
+            assert abs(pops - s["pops"]) <= max(2, 0.01 * s["pops"])
+    assert n == 384
+
+
 def test_inner_bnb_trimmed(oracle_mod, oracle_dt_bunny, bunny_data10):
     """trimFraction = 0.1 (GoICP::trimFraction set in the harness): the reference's own trimmed InnerBnB
     (jly_goicp.cpp:293-315).  Single expansions rel 1e-4 + same arg-min child; full searches: value rel

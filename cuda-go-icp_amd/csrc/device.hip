@@ -1948,6 +1948,46 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 	return hipGetLastError();
 }
 
+// min over n floats and the first index that attains it (what a search does with the upper bounds of a batch: the incumbent
+// is the smallest ub, first child on ties -- bnb_queue_kernel's digest; exposed so that a caller driving goicp_eval_bounds_device
+// itself, like bench.py's step, reduces with the library's own code).  One workgroup: 65 536 values are 64 per thread.
+__global__ __launch_bounds__(1024) void reduce_min_kernel(const float* __restrict__ v, int n, float* __restrict__ out_min, int* __restrict__ out_idx)
+{
+	__shared__ float sv[16];
+	__shared__ int si[16];
+	float best = __builtin_inff();
+	int bi = 0x7fffffff;
+	for (int i = threadIdx.x * 4; i < n; i += 4096) {
+		if (i + 3 < n) {
+			const float4 x = *reinterpret_cast<const float4*>(v + i);
+			if (x.x < best) { best = x.x; bi = i; }
+			if (x.y < best) { best = x.y; bi = i + 1; }
+			if (x.z < best) { best = x.z; bi = i + 2; }
+			if (x.w < best) { best = x.w; bi = i + 3; }
+		} else
+			for (int k = i; k < n; k++) if (v[k] < best) { best = v[k]; bi = k; }
+	}
+	for (int off = 32; off; off >>= 1) {
+		const float ov = __shfl_xor(best, off);
+		const int oi = __shfl_xor(bi, off);
+		if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+	}
+	if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 16; w++) if (sv[w] < best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+		out_min[0] = best;
+		if (out_idx) out_idx[0] = bi;
+	}
+}
+
+hipError_t launch_reduce_min(const float* v, int n, float* out_min, int* out_idx, hipStream_t stream)
+{
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(reduce_min_kernel, dim3(1), dim3(1024), 0, stream, v, n, out_min, out_idx);
+	return hipGetLastError();
+}
+
 template <int K, int LAYOUT>
 __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, DtDesc dt,
                                                                int32_t* __restrict__ idx, float* __restrict__ d2)

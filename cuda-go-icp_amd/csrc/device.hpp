@@ -167,6 +167,9 @@ hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t st
 hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2,
                            hipStream_t stream);
 
+// min of n floats (+ first index attaining it, may be null): one workgroup; v must be 16-byte aligned
+hipError_t launch_reduce_min(const float* v, int n, float* out_min, int* out_idx, hipStream_t stream);
+
 // ---- test / measurement helpers ---------------------------------------------------------------
 hipError_t launch_kabsch_debug(const float* d_H9, float* d_R9, hipStream_t stream);
 // window: floats per workgroup window (power of two >= 4096, <= grid size); 8*iters loads per lane

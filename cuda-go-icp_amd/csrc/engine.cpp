@@ -584,6 +584,12 @@ void Engine::eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, 
 	cnt_.bounds_launches++;
 }
 
+void Engine::reduce_min_dev(const float* d_v, int n, float* d_min, int* d_idx, hipStream_t s)
+{
+	DeviceGuard guard(dev_);
+	HIPCHK(launch_reduce_min(d_v, n, d_min, d_idx, s ? s : stream_));
+}
+
 float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters)
 {
 	DeviceGuard guard(dev_);

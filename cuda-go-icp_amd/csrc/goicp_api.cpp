@@ -249,6 +249,14 @@ int goicp_eval_bounds_device(goicp_handle h, const void* d_rots, const void* d_c
 	});
 }
 
+int goicp_reduce_min_device(goicp_handle h, const void* d_values, size_t n, void* d_min, void* d_argmin, void* stream)
+{
+	REQUIRE(h && d_values && d_min && n > 0 && n <= 0x7fffffffu && ((uintptr_t)d_values & 15) == 0);
+	return guarded([&] {
+		h->e->reduce_min_dev(static_cast<const float*>(d_values), (int)n, static_cast<float*>(d_min), static_cast<int*>(d_argmin), static_cast<hipStream_t>(stream));
+	});
+}
+
 int goicp_time_bounds_device(goicp_handle h, const void* d_rots, const void* d_cubes, size_t B, void* d_ub, void* d_lb,
                              int32_t iters, float* ms)
 {

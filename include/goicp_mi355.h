@@ -183,6 +183,10 @@ int goicp_eval_bounds_batch(goicp_handle h, const float* rots /* K x 9 */, size_
  * hipStream_t (NULL = the engine's own stream); asynchronous. */
 int goicp_eval_bounds_device(goicp_handle h, const void* d_rots, const void* d_cubes, size_t B,
                              void* d_ub, void* d_lb, void* stream);
+/* min of n device floats and (d_argmin != NULL) the first index attaining it -- what a search does with a batch's upper
+ * bounds (incumbent = smallest ub, first child on ties: jly_goicp.cpp:319-324); one workgroup, asynchronous on `stream`
+ * (NULL = the engine's own).  d_values must be 16-byte aligned. */
+int goicp_reduce_min_device(goicp_handle h, const void* d_values, size_t n, void* d_min, void* d_argmin, void* stream);
 /* average duration (ms, HIP events on the launch stream) of `iters` back-to-back launches */
 int goicp_time_bounds_device(goicp_handle h, const void* d_rots, const void* d_cubes, size_t B,
                              void* d_ub, void* d_lb, int32_t iters, float* ms_per_launch);

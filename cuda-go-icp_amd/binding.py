@@ -35,7 +35,8 @@ class CParams(C.Structure):
                 ("morton_sort", C.c_int32), ("rot_batch", C.c_int32), ("kd_gpu_build", C.c_int32), ("trim_fraction", C.c_float),
                 ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
                 ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32),
-                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("flow", C.c_int32), ("adaptive_k", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32)]
+                ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("flow", C.c_int32), ("adaptive_k", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32),
+                ("lds_tiles", C.c_int32), ("tile_spread_vox", C.c_float), ("tile_min", C.c_int32)]
 
 
 class CCube(C.Structure):
@@ -45,7 +46,7 @@ class CCube(C.Structure):
 
 class CCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rot_pops", "trans_pops", "cubes", "inner_calls", "icp_runs", "icp_iters",
-                                         "bounds_launches", "queue_fallbacks")]
+                                         "bounds_launches", "queue_fallbacks", "tile_expansions")]
 
 
 class CResult(C.Structure):
@@ -156,7 +157,8 @@ SYMBOLS = {
 
 
 def library_path():
-    return os.path.join(HERE, "libgoicp_mi355.so")
+    # GOICP_LIBRARY: experiments load a variant build (tools/); the product and the tests load the in-tree library
+    return os.environ.get("GOICP_LIBRARY") or os.path.join(HERE, "libgoicp_mi355.so")
 
 
 def build_library(force=False):

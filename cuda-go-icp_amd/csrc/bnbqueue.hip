@@ -46,6 +46,8 @@ struct QShared {
 	unsigned push_tot[kQThreads / 64];
 	int n_sel, n_holes, parent_off, bcast;
 	int hole_cnt[2], fill_cnt[2];
+	float ext[2][6];                               // tile-list test: min / max corner of the selected nodes, per wavefront
+	float ext_w[2];
 	unsigned char tail_sel[kQueueMaxPop];          // removal: is tail position m + t one of the selected nodes?
 	float psum[2 * kQThreads];                     // digest: partial sums of the chunk partials, [child][part] for ub, then for lb
 };
@@ -69,14 +71,14 @@ __device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, floa
 __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
                                                               const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
                                                               const float* __restrict__ ubs, const float* __restrict__ lbs,
-                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity)
+                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile)
 {
 	__shared__ QShared sh;
 	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	QSearch* __restrict__ S = searches + s;
 	QNode* __restrict__ Q = q + (size_t)s * kQueueCap;
 	if (s == 0 && tid < 8) {
-		if (tid == 0) ctl->n_groups[parity ^ 1] = 0;                  // the next round's counter (its last reader has finished)
+		if (tid == 0) { ctl->n_groups[parity ^ 1] = 0; ctl->n_tile_groups[parity ^ 1] = 0; ctl->n_tile_segs[parity ^ 1] = 0; }   // the next round's counters (their last readers have finished)
 		ctl->work[parity][tid] = 0;                                   // this round's work counters of the bound evaluation
 	}
 	if (S->done) return;
@@ -90,11 +92,13 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	if (n_prev > 0) {
 		const int C = 8 * n_prev, off = S->parent_off;
 		const bool mine = tid < C;
+		// the previous round listed this search's expansions in the tile list: its bounds, partial sums and records live there
+		if (S->tile) { prev_parents = tile.parents[parity ^ 1]; ubs = tile.ub; lbs = tile.lb; scratch = tile.scratch; }
+		const int chunks = S->tile ? ctl->tile_chunks : ctl->chunks;
 		// The evaluation split the cloud into `chunks` chunks: its per-chunk sums are added here (this replaces a finalize launch
 		// per round).  Small rounds have few children and many chunks (up to 118), so the sum is spread over the workgroup: P
 		// threads per child add every P-th chunk partial, the child's own thread adds the P results in order.  Fixed order
 		// for given (children, chunks): deterministic.
-		const int chunks = ctl->chunks;
 		const int P = chunks > 1 ? max(1, min(chunks, kQThreads / C)) : 1;
 		if (chunks > 1) {
 			if (tid < C * P) {
@@ -375,15 +379,52 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		if (tid == 0) { S->best = best; S->count = n; S->n_parents = 0; S->done = 1; S->pops += 1; }
 		return;
 	}
-	if (tid == 0) sh.parent_off = atomicAdd(&ctl->n_groups[parity], n_sel);
+	// ---- which list: the tile list takes a search whose selected nodes lie within a few voxels of each other (then the DT box
+	// a 64-point patch of the cloud can reach under ALL of them fits the LDS tile) and that has enough of them to fill lanes ----
+	QNode mine_nd{};
+	if (tid < n_sel) mine_nd = Q[sh.sel_pos[tid]];
+	bool to_tile = false;
+	if (n_sel >= qp.tile_min && qp.tile_spread > 0.f) {
+		float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0.f;
+		if (tid < n_sel) { lo3[0] = hi3[0] = mine_nd.x; lo3[1] = hi3[1] = mine_nd.y; lo3[2] = hi3[2] = mine_nd.z; wmax = mine_nd.w; }
+		if (wave < 2) {
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+				for (int k = 0; k < 3; k++) { lo3[k] = fminf(lo3[k], __shfl_xor(lo3[k], o, 64)); hi3[k] = fmaxf(hi3[k], __shfl_xor(hi3[k], o, 64)); }
+				wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+			}
+			if (lane == 0) {
+#pragma unroll
+				for (int k = 0; k < 3; k++) { sh.ext[wave][k] = lo3[k]; sh.ext[wave][3 + k] = hi3[k]; }
+				sh.ext_w[wave] = wmax;
+			}
+		}
+		__syncthreads();
+		float spread = 0.f;
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			spread = fmaxf(spread, fmaxf(sh.ext[0][3 + k], sh.ext[1][3 + k]) - fminf(sh.ext[0][k], sh.ext[1][k]));
+		spread += fmaxf(sh.ext_w[0], sh.ext_w[1]);                      // the children's centres reach w/4 .. 3w/4 beyond the corners
+		to_tile = spread <= qp.tile_spread;
+		if (to_tile && tid == 0) atomicAdd(&ctl->tile_hint, 1);
+		to_tile = to_tile && qp.tile_on != 0;
+	}
+	if (tid == 0) {
+		if (to_tile) {
+			const int nseg = (n_sel + 63) >> 6;
+			sh.parent_off = atomicAdd(&ctl->n_tile_groups[parity], n_sel);
+			atomicAdd(&ctl->tile_total, n_sel);
+			const int seg0 = atomicAdd(&ctl->n_tile_segs[parity], nseg);
+			for (int k = 0; k < nseg; k++) tile.segs[parity][seg0 + k] = TileSeg{sh.parent_off + 64 * k, min(64, n_sel - 64 * k), S->rot};
+		} else
+			sh.parent_off = atomicAdd(&ctl->n_groups[parity], n_sel);
+	}
 	__syncthreads();
 	const int off = sh.parent_off;
 	const float coeff = S->coeff;
 	const int rot = S->rot;
-	if (tid < n_sel) {
-		const QNode nd = Q[sh.sel_pos[tid]];
-		parents[off + tid] = ParentRec{nd.x, nd.y, nd.z, nd.w, coeff, rot};
-	}
+	if (tid < n_sel) (to_tile ? tile.parents[parity] : parents)[off + tid] = ParentRec{mine_nd.x, mine_nd.y, mine_nd.z, mine_nd.w, coeff, rot};
 	__syncthreads();
 	// remove the selected nodes: the holes among the first m = n - n_sel positions are filled, in order, with the
 	// unselected nodes of the tail [m, n)  (at most n_sel <= 128 of each: the first two wavefronts do it)
@@ -410,7 +451,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		__syncthreads();
 		if (filler) Q[sh.hole_pos[frank]] = moved;
 	}
-	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; }
+	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; S->tile = to_tile ? 1 : 0; }
 }
 
 __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, int nsearch, QParams qp, QCtl* __restrict__ ctl)
@@ -419,12 +460,13 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 	if (s == 0) {
 		ctl->n_groups[0] = 0; ctl->n_groups[1] = 0; ctl->overflow = 0;
 		for (int k = 0; k < 8; k++) { ctl->work[0][k] = 0; ctl->work[1][k] = 0; }
+		ctl->n_tile_groups[0] = ctl->n_tile_groups[1] = 0; ctl->n_tile_segs[0] = ctl->n_tile_segs[1] = 0; ctl->tile_chunks = 1; ctl->tile_hint = 0; ctl->tile_total = 0;
 	}
 	if (s >= nsearch) return;
 	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241
 	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0;
 }
 
 // the listed slots become fresh searches (continuous flow: slots are recycled while other searches keep running)
@@ -437,7 +479,7 @@ __global__ void bnb_init_list_kernel(QSearch* __restrict__ searches, QNode* __re
 	QSearch& S = searches[in.slot];
 	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot;
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0;
 }
 
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream)
@@ -455,11 +497,15 @@ hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QPara
 }
 
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream)
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile)
 {
 	if (nsearch <= 0) return hipSuccess;
 	if (qp.K < 1 || qp.K > kQueueMaxPop) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, qp, prev_parents, parents, ubs, lbs, scratch, ctl, parity);
+	QTile t{};
+	QParams q2 = qp;
+	if (tile && tile->ub) t = *tile;
+	else { q2.tile_on = 0; }                                               // no buffers: nothing may be listed there
+	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t);
 	return hipGetLastError();
 }
 

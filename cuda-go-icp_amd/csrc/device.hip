@@ -176,6 +176,9 @@ __device__ __forceinline__ void load_group(const CubeRec* __restrict__ cubes, co
 // (one rotation, per axis two translation values): 6 voxel indices instead of 24.  Every value is the same
 // float expression as in the generic per-cube path, so the results are bit-identical.
 struct SiblingSet { float tx0, tx1, ty0, ty1, tz0, tz1; };
+// rp = R p already formed (xyz)
+template <int LAYOUT>
+__device__ __forceinline__ void sibling_residuals_rotated(const DtDesc& dt, const float4& rp, const SiblingSet& t, float rho, float m[kGroup]);
 template <int LAYOUT>
 __device__ __forceinline__ void sibling_residuals(const DtDesc& dt, const Rot9& R0, const SiblingSet& t, const float4& p, float rho,
                                                   float m[kGroup])
@@ -183,6 +186,12 @@ __device__ __forceinline__ void sibling_residuals(const DtDesc& dt, const Rot9& 
 	const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
 	const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
 	const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+	sibling_residuals_rotated<LAYOUT>(dt, make_float4(rx, ry, rz, p.w), t, rho, m);
+}
+template <int LAYOUT>
+__device__ __forceinline__ void sibling_residuals_rotated(const DtDesc& dt, const float4& rp, const SiblingSet& t, float rho, float m[kGroup])
+{
+	const float rx = rp.x, ry = rp.y, rz = rp.z;
 	const float qx[2] = {rx + t.tx0, rx + t.tx1}, qy[2] = {ry + t.ty0, ry + t.ty1}, qz[2] = {rz + t.tz0, rz + t.tz1};
 	bool risky = false;
 	int ix[2], iy[2], iz[2];
@@ -352,13 +361,38 @@ __device__ __forceinline__ void bounds_work(
 // Every per-point value is the same float expression as in bounds_work (voxel_fast / voxel_exact, the same clamp and
 // subtraction order); lookups that fall outside the staged box (or outside the grid) take dt_distance from global memory.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTileFloats = 8192;                 // 32 KB: up to 128 bricks of 4x4x4 voxels
+#ifndef GOICP_TILE_FLOATS
+#define GOICP_TILE_FLOATS 8192
+#endif
+constexpr int kTileFloats = GOICP_TILE_FLOATS;    // 32 KB: up to 128 bricks of 4x4x4 voxels
 constexpr int kTilePatch = 64;                    // points per staged box
-struct TileSeg { int off, n, rot; };              // a search's expansions parents[off .. off+n), n <= 64, one rotation
+typedef float f2 __attribute__((ext_vector_type(2)));
+// split of the cloud for `nseg` tile segments on a grid of `grid` workgroups: as many chunks (multiples of the 64-point
+// sub-patch) as it takes to give every workgroup an item, at most one sub-patch per chunk
+__host__ __device__ inline void tile_shape(int nseg, int N, int grid, int* chunks, int* chunk_pts)
+{
+	const int patches = (N + kTilePatch - 1) / kTilePatch;
+	int c = nseg > 0 ? (grid + nseg - 1) / nseg : 1;
+	if (c < 1) c = 1;
+	if (c > patches) c = patches;
+	int cp = (patches + c - 1) / c * kTilePatch;
+	c = (N + cp - 1) / cp;
+	*chunks = c; *chunk_pts = cp;
+}
 
+// Round 3: the staged box is kept in LDS as a plain [z][y][x] array (brick-aligned origin and dimensions, so that it is
+// still filled brick by brick with coalesced 16-byte loads), and a sub-patch whose box lies wholly inside the grid -- the
+// usual case: the grid is the target's bounding cube expanded twice -- takes a path with NO per-lookup checks at all: the
+// box contains, by construction, every voxel any lane can index for any of the 64 points, so a lookup is three
+// multiply-adds, one three-operand add per child and a ds_read_b32; the eight children are accumulated as four pairs
+// (x-siblings) in packed fp32 (v_pk_add / v_pk_mul -- same per-element operations and order as the scalar code:
+// bit-identical).  Round 2's form computed brick offsets with a bounds check per axis and child (42 + 16 of its ~180
+// vector instructions per point and lane, plus the branches around eight inlined global fallbacks).
+template <bool QUEUED>
 __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
-                                                          const ParentRec* __restrict__ parents, const TileSeg* __restrict__ segs, int nseg, int chunks,
-                                                          int chunk_pts, float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out,
+                                                          const ParentRec* __restrict__ parents, const TileSeg* __restrict__ segs, int nseg_host, int chunks_host,
+                                                          int chunk_pts_host, const int* __restrict__ d_nseg, int* __restrict__ d_chunks,
+                                                          float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out,
                                                           unsigned* __restrict__ stats)
 {
 	__shared__ float tile[kTileFloats];
@@ -366,20 +400,35 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 	static_assert(4 * 64 * 2 * kGroup <= kTileFloats, "the wavefront sums reuse the tile");
 	float (*wacc)[64][2 * kGroup] = reinterpret_cast<float (*)[64][2 * kGroup]>(tile);   // after the last sub-patch
 	__shared__ float tr[6];                       // translation range of the search's siblings: min xyz, max xyz
-	__shared__ int box[7];                        // brick origin bx0 by0 bz0, brick dims TX TY TZ, staged flag
-	__shared__ int red_i[4][6];
-	const int seg = blockIdx.x / chunks, chunk = blockIdx.x - seg * chunks;
-	if (seg >= nseg) return;
+	__shared__ int box[8];                        // voxel origin x0 y0 z0, voxel dims DX DY DZ (multiples of 4), staged, wholly inside the grid
+	int nseg = nseg_host, chunks = chunks_host, chunk_pts = chunk_pts_host;
+	if (QUEUED) {
+		// the number of segments is known to the device only (bnb_queue_kernel counted them): the split of the cloud follows from it
+		nseg = *d_nseg;
+		if (nseg <= 0) return;
+		tile_shape(nseg, N, (int)gridDim.x, &chunks, &chunk_pts);
+		if (blockIdx.x == 0 && threadIdx.x == 0) *d_chunks = chunks;      // the next round's digest adds the chunk partials up
+	}
+	for (int item = blockIdx.x; item < nseg * chunks; item += QUEUED ? (int)gridDim.x : nseg * chunks) {
+	const int seg = item / chunks, chunk = item - seg * chunks;
 	const TileSeg sg = segs[seg];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const bool live = lane < sg.n;
+	// A segment of n <= 32 expansions does not fill a wavefront with one expansion per lane: the lanes are dealt P = 2^ceil(log2 n)
+	// expansions x L = 64 / P point subsets instead (lane = sub * P + e; lane group `sub` takes every L-th point of the wavefront's
+	// share), and the L partial sums of an expansion are added at the end (xor shuffles, fixed order) -- at least half of the
+	// lanes work for any n.
+	int P = 1;
+	while (P < sg.n) P <<= 1;
+	const int L = 64 / P, e_lane = lane & (P - 1), sub = lane / P;
+	const bool live = e_lane < sg.n;
 	// this lane's expansion: corner + (bit)*w' + w'/2 per axis (load_group's float operations)
-	const ParentRec pr = parents[sg.off + (live ? lane : 0)];
+	const ParentRec pr = parents[sg.off + (live ? e_lane : 0)];
 	const float w = pr.w / 2;
 	const float delta = (float)(1.732050808 / 2.0 * (double)w);
 	const SiblingSet ts{pr.x + w / 2, pr.x + w + w / 2, pr.y + w / 2, pr.y + w + w / 2, pr.z + w / 2, pr.z + w + w / 2};
 	const float coeff = pr.coeff;
 	const Rot9 R0 = rots[sg.rot];
+	__syncthreads();                              // (queued form: the previous item's sums have been read out of the tile)
 	if (wave == 0) {
 		float mn[3] = {ts.tx0, ts.ty0, ts.tz0}, mx[3] = {ts.tx1, ts.ty1, ts.tz1};
 #pragma unroll
@@ -390,9 +439,10 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 			if (lane == 0) { tr[k] = mn[k]; tr[3 + k] = mx[k]; }
 		}
 	}
-	float ub[kGroup], lb[kGroup];
+	f2 ub2[4], lb2[4];
 #pragma unroll
-	for (int c = 0; c < kGroup; c++) { ub[c] = 0.f; lb[c] = 0.f; }
+	for (int k = 0; k < 4; k++) { ub2[k] = f2{0.f, 0.f}; lb2[k] = f2{0.f, 0.f}; }
+	const f2 delta2 = f2{delta, delta};
 	const int p0 = chunk * chunk_pts, p1 = p0 + chunk_pts < N ? p0 + chunk_pts : N;
 	__syncthreads();
 	for (int s0 = p0; s0 < p1; s0 += kTilePatch) {
@@ -419,80 +469,112 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 				for (int o = 32; o > 0; o >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = max(hi[k], __shfl_xor(hi[k], o, 64)); }
 			}
 			if (threadIdx.x == 0) {
-				int b0[3], nb[3];
-				bool ok = true;
+				// the box in LDS: x brick-aligned (it is filled with 16-byte pieces of brick rows), y and z exact
+				bool inside = true;
 #pragma unroll
-				for (int k = 0; k < 3; k++) {
-					const int l = max(lo[k], 0) >> 2, h = min(hi[k], dt.V - 1) >> 2;
-					b0[k] = l; nb[k] = h - l + 1;
-					ok = ok && nb[k] > 0;
-				}
-				ok = ok && (long long)nb[0] * nb[1] * nb[2] * 64 <= kTileFloats;
-				box[0] = b0[0]; box[1] = b0[1]; box[2] = b0[2]; box[3] = nb[0]; box[4] = nb[1]; box[5] = nb[2]; box[6] = ok ? 1 : 0;
+				for (int k = 0; k < 3; k++) inside = inside && lo[k] >= 0 && hi[k] <= dt.V - 1;
+				const int x0 = lo[0] & ~3, DX = ((hi[0] | 3) + 1) - x0, DY = hi[1] - lo[1] + 1, DZ = hi[2] - lo[2] + 1;
+				const bool ok = inside && (long long)DX * DY * DZ <= kTileFloats;
+				box[0] = x0; box[1] = lo[1]; box[2] = lo[2]; box[3] = DX; box[4] = DY; box[5] = DZ;
+				box[6] = ok ? 1 : 0; box[7] = ok ? 1 : 0;
 				if (stats) atomicAdd(&stats[ok ? 0 : 1], 1u);
 			}
 		}
 		__syncthreads();
-		const int bx0 = box[0], by0 = box[1], bz0 = box[2], TX = box[3], TY = box[4], TZ = box[5];
-		const bool staged = box[6] != 0;
-		if (staged) {
-			const int n4 = TX * TY * TZ * 16;                             // float4 pieces
+		const int x0 = box[0], y0 = box[1], z0 = box[2], DX = box[3], DY = box[4], DZ = box[5];
+		const bool fast = box[7] != 0;
+		if (fast) {
+			// every brick the box touches is read whole (16 consecutive lanes = one 256-byte brick: coalesced), the pieces inside
+			// the box are kept
+			const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
+			const int nbx = DX >> 2, nby = ((y0 + DY - 1) >> 2) - by0 + 1, nbz = ((z0 + DZ - 1) >> 2) - bz0 + 1;
+			const int n4 = nbx * nby * nbz * 16;
 			for (int idx = threadIdx.x; idx < n4; idx += 256) {
 				const int b = idx >> 4, part = idx & 15;
-				const int bx = b % TX, t2 = b / TX, by = t2 % TY, bz = t2 / TY;
+				const int bx = b % nbx, t2 = b / nbx, by = t2 % nby, bz = t2 / nby;
+				const int y = (by0 + by) * 4 + (part & 3) - y0, z = (bz0 + bz) * 4 + (part >> 2) - z0;
 				const size_t gb = ((size_t)(bz0 + bz) * dt.VB + (by0 + by)) * dt.VB + (bx0 + bx);
-				reinterpret_cast<float4*>(tile)[idx] = reinterpret_cast<const float4*>(dt.grid)[gb * 16 + part];
+				const float4 v = reinterpret_cast<const float4*>(dt.grid)[gb * 16 + part];
+				if ((unsigned)y < (unsigned)DY && (unsigned)z < (unsigned)DZ) *reinterpret_cast<float4*>(&tile[(z * DY + y) * DX + bx * 4]) = v;
 			}
 		}
 		__syncthreads();
 		// ---- every wavefront: its 16 points x this lane's 8 siblings ----
-		if (live)
-		for (int j = wave; j < np; j += 4) {
-			const float4 q = rp[j];                                       // same address in every lane: a broadcast read
-			const float qx[2] = {q.x + ts.tx0, q.x + ts.tx1}, qy[2] = {q.y + ts.ty0, q.y + ts.ty1}, qz[2] = {q.z + ts.tz0, q.z + ts.tz1};
-			bool risky = false;
-			int ix[2], iy[2], iz[2];
+		if (live) {
+			if (fast) {
+				// byte address in the tile = 4 (ix - x0) + 4 DX (iy - y0) + 4 DX DY (iz - z0)
+				const int sy = 4 * DX, sz = 4 * DX * DY;
+				const int cx = -4 * x0, cy = -sy * y0, cz = -sz * z0;
+				const char* tb = reinterpret_cast<const char*>(tile);
+				for (int j = wave + 4 * sub; j < np; j += 4 * L) {
+					const float4 q = rp[j];                               // one address per lane group: a broadcast read
+					const float qx[2] = {q.x + ts.tx0, q.x + ts.tx1}, qy[2] = {q.y + ts.ty0, q.y + ts.ty1}, qz[2] = {q.z + ts.tz0, q.z + ts.tz1};
+					// six voxel indices: F = (q - min) * scale + 0.5 in float; the float index is provably the reference's unless F is
+					// within eps(F) = c1 + c2 |F| of an integer (voxel_fast) -- ONE test on the smallest margin of the six
+					float F[6] = {__fmaf_rn(qx[0] - dt.xmin_f, dt.scale_f, 0.5f), __fmaf_rn(qx[1] - dt.xmin_f, dt.scale_f, 0.5f),
+					              __fmaf_rn(qy[0] - dt.ymin_f, dt.scale_f, 0.5f), __fmaf_rn(qy[1] - dt.ymin_f, dt.scale_f, 0.5f),
+					              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
+					float margin[6];
 #pragma unroll
-			for (int k = 0; k < 2; k++) {
-				ix[k] = voxel_fast(qx[k], dt.xmin_f, dt.scale_f, dt.c1, dt.c2, risky);
-				iy[k] = voxel_fast(qy[k], dt.ymin_f, dt.scale_f, dt.c1, dt.c2, risky);
-				iz[k] = voxel_fast(qz[k], dt.zmin_f, dt.scale_f, dt.c1, dt.c2, risky);
-			}
-			if (risky) {
+					for (int k = 0; k < 6; k++) margin[k] = fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1);
+					const float worst = fminf(fminf(fminf(margin[0], margin[1]), fminf(margin[2], margin[3])), fminf(margin[4], margin[5]));
+					int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
+					if (worst <= 0.f) {
 #pragma unroll
-				for (int k = 0; k < 2; k++) {
-					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
-					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
-					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+						for (int k = 0; k < 2; k++) {
+							ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+							iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+							iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+						}
+					}
+					const int ax[2] = {4 * ix[0] + cx, 4 * ix[1] + cx};
+					const int ay[2] = {__mul24(iy[0], sy) + cy, __mul24(iy[1], sy) + cy};
+					const int az[2] = {__mul24(iz[0], sz) + cz, __mul24(iz[1], sz) + cz};
+					const float rho = coeff * q.w;
+					const f2 rho2 = f2{rho, rho};
+#pragma unroll
+					for (int k = 0; k < 4; k++) {                         // pair k: children 2k (x0) and 2k + 1 (x1) of y[(k & 1)], z[(k >> 1)]
+						const int yz = ay[k & 1] + az[k >> 1];
+						f2 v = f2{*reinterpret_cast<const float*>(tb + (ax[0] + yz)), *reinterpret_cast<const float*>(tb + (ax[1] + yz))};
+						v = v - rho2;
+						const f2 m = __builtin_elementwise_max(v, f2{0.f, 0.f});
+						ub2[k] = ub2[k] + m * m;
+						const f2 dis = __builtin_elementwise_max(m - delta2, f2{0.f, 0.f});
+						lb2[k] = lb2[k] + dis * dis;
+					}
 				}
-			}
-			unsigned fx[2], fy[2], fz[2];
+			} else {
+				// the box is too large for the tile, or reaches over the edge of the grid: the direct kernel's sibling path (eight
+				// gathers in flight per point, out-of-grid extension included) -- same per-point expressions
+				for (int j = wave + 4 * sub; j < np; j += 4 * L) {
+					const float4 q = rp[j];
+					float m[kGroup];
+					sibling_residuals_rotated<1>(dt, q, ts, coeff * q.w, m);
 #pragma unroll
-			for (int k = 0; k < 2; k++) {
-				const int ax = (ix[k] >> 2) - bx0, ay = (iy[k] >> 2) - by0, az = (iz[k] >> 2) - bz0;
-				fx[k] = staged && (unsigned)ax < (unsigned)TX ? ((unsigned)ax << 6) | ((unsigned)ix[k] & 3u) : kOutside;
-				fy[k] = staged && (unsigned)ay < (unsigned)TY ? ((unsigned)(ay * TX) << 6) | (((unsigned)iy[k] & 3u) << 2) : kOutside;
-				fz[k] = staged && (unsigned)az < (unsigned)TZ ? ((unsigned)(az * TX * TY) << 6) | (((unsigned)iz[k] & 3u) << 4) : kOutside;
-			}
-			const float rho = coeff * q.w;
-#pragma unroll
-			for (int c = 0; c < kGroup; c++) {
-				const unsigned e = fx[c & 1] + fy[(c >> 1) & 1] + fz[(c >> 2) & 1];
-				float v;
-				if (e < kOutside) v = tile[e];
-				else v = dt_distance<1>(dt, qx[c & 1], qy[(c >> 1) & 1], qz[(c >> 2) & 1]);     // outside the box or the grid
-				v = v - rho;
-				const float m = v < 0.f ? 0.f : v;
-				ub[c] += m * m;
-				const float dis = fmaxf(m - delta, 0.f);
-				lb[c] += dis * dis;
+					for (int k = 0; k < 4; k++) {
+						const f2 m2 = f2{m[2 * k], m[2 * k + 1]};
+						ub2[k] = ub2[k] + m2 * m2;
+						const f2 dis = __builtin_elementwise_max(m2 - delta2, f2{0.f, 0.f});
+						lb2[k] = lb2[k] + dis * dis;
+					}
+				}
 			}
 		}
 		__syncthreads();                                                  // the box is restaged by the next sub-patch
 	}
-	// ---- the four wavefronts' sums, in wavefront order ----
+	// ---- the lane groups' partial sums of an expansion (L > 1), then the four wavefronts' sums, in fixed order ----
+	for (int off = P; off < 64; off <<= 1) {
 #pragma unroll
-	for (int c = 0; c < kGroup; c++) { wacc[wave][lane][c] = ub[c]; wacc[wave][lane][kGroup + c] = lb[c]; }
+		for (int k = 0; k < 4; k++) {
+			ub2[k].x += __shfl_xor(ub2[k].x, off, 64); ub2[k].y += __shfl_xor(ub2[k].y, off, 64);
+			lb2[k].x += __shfl_xor(lb2[k].x, off, 64); lb2[k].y += __shfl_xor(lb2[k].y, off, 64);
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		wacc[wave][lane][2 * k] = ub2[k].x; wacc[wave][lane][2 * k + 1] = ub2[k].y;
+		wacc[wave][lane][kGroup + 2 * k] = lb2[k].x; wacc[wave][lane][kGroup + 2 * k + 1] = lb2[k].y;
+	}
 	__syncthreads();
 	for (int idx = threadIdx.x; idx < sg.n * 2 * kGroup; idx += 256) {
 		const int e = idx >> 4, k = idx & 15;
@@ -500,6 +582,7 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 		const int group = sg.off + e;
 		if (chunks == 1) (k < kGroup ? ub_out : lb_out)[group * kGroup + (k & (kGroup - 1))] = s;
 		else scratch[((size_t)group * chunks + chunk) * (2 * kGroup) + k] = s;
+	}
 	}
 }
 
@@ -511,12 +594,26 @@ hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const 
 	if (dt.layout != 1 || n < 1 || n > 64 || nseg < 1 || chunks < 1) return hipErrorInvalidValue;
 	int cp = (N + chunks - 1) / chunks;
 	cp = (cp + kTilePatch - 1) / kTilePatch * kTilePatch;
-	hipLaunchKernelGGL(bounds_tile_kernel, dim3(nseg * chunks), dim3(256), 0, stream, src, N, dt, rots, parents, static_cast<const TileSeg*>(segs), nseg, chunks, cp,
-	                   scratch, ub, lb, stats);
+	hipLaunchKernelGGL(bounds_tile_kernel<false>, dim3(nseg * chunks), dim3(256), 0, stream, src, N, dt, rots, parents, static_cast<const TileSeg*>(segs), nseg, chunks, cp,
+	                   static_cast<const int*>(nullptr), static_cast<int*>(nullptr), scratch, ub, lb, stats);
 	if (chunks > 1) {
 		const int groups = nseg * n, t = groups * 2 * kGroup;
 		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, groups * kGroup, groups, chunks, ub, lb);
 	}
+	return hipGetLastError();
+}
+
+constexpr int kTileQueueGrid = 256 * (160 * 1024 / (kTileFloats * 4 + 2048));   // as many workgroups per CU as their LDS allows (32 KB tiles: four)
+size_t bounds_tile_queue_scratch_floats(int max_groups)
+{
+	// groups x chunks x 16 with chunks <= ceil(grid / segments) and groups <= 64 segments: at most 64 (grid + segments) rows
+	return (size_t)64 * ((size_t)kTileQueueGrid + (size_t)max_groups) * 2 * kGroup;
+}
+hipError_t launch_bounds_tile_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const QTile& tile, QCtl* ctl, int parity, hipStream_t stream)
+{
+	if (dt.layout != 1 || N <= 0) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(bounds_tile_kernel<true>, dim3(kTileQueueGrid), dim3(256), 0, stream, src, N, dt, rots, tile.parents[parity], tile.segs[parity], 0, 1, 0,
+	                   &ctl->n_tile_segs[parity], &ctl->tile_chunks, tile.scratch, tile.ub, tile.lb, static_cast<unsigned*>(nullptr));
 	return hipGetLastError();
 }
 

@@ -93,13 +93,27 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 	int32_t n_parents, parent_off;  // this round's expansions in the round's list
 	int32_t pops, cubes;            // tNodeCount of this search / children evaluated
 	float bx, by, bz, bw;           // best child (corner, width), valid when improved
+	int32_t tile, pad;              // this round's expansions are in the tile list (parent_off counts in that list)
 };
+struct TileSeg { int32_t off, n, rot; };   // tile list: a search's expansions parents[off .. off+n), n <= 64, one rotation
 struct QCtl {
 	int32_t n_groups[2];            // expansions listed per round parity
 	int32_t overflow;
 	int32_t chunks;                 // point chunks per expansion of the last bound evaluation: > 1 -> its sums are chunk partials in the scratch block,
 	                                // added up by the next round's digest (bnb_queue_kernel) -- no separate finalize launch
 	int32_t work[2][8];             // per round parity and XCD slot: next work item of the bound evaluation (dynamic distribution)
+	// second expansion list of a round (LDS-staged DT tiles, device.hip bounds_tile_kernel): the searches whose selected nodes lie
+	// close together -- a few voxels -- are listed here instead and evaluated from DT boxes staged in LDS
+	int32_t n_tile_groups[2];       // expansions in the tile list per round parity
+	int32_t n_tile_segs[2];         // segments (<= 64 expansions of one search) per round parity
+	int32_t tile_chunks;            // point chunks per segment of the last tile evaluation (its sums are chunk partials when > 1)
+	int32_t tile_hint;              // running count of (search, round) pairs that qualified for the tile list, whether it was on or not
+	int32_t tile_total;             // running count of expansions listed in the tile list
+};
+struct QTile {                      // buffers of the tile list (all null / zero: tiles off)
+	ParentRec* parents[2];
+	TileSeg* segs[2];
+	float* ub; float* lb; float* scratch;
 };
 struct QParams {
 	float thr;                      // SSEThresh
@@ -108,13 +122,19 @@ struct QParams {
 	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
 	int32_t cap;                    // nodes a queue may hold (<= kQueueCap; smaller values only to exercise the overflow path)
 	float lo[3], hi[3];
+	int32_t tile_on;                // 1: searches that qualify are listed in the tile list this round (its evaluation is launched)
+	int32_t tile_min;               // fewest expansions for the tile list (a lane group of the tile kernel = one expansion)
+	float tile_spread;              // largest extent, per axis, of the selected nodes' translations (world units) for the tile list
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
 struct QInit { int32_t slot; float best; float coeff; int32_t rot; };
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream);
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream);
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile = nullptr);
+// bounds of the tile list of round `parity` (segment count known to the device only); fixed grid
+hipError_t launch_bounds_tile_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const QTile& tile, QCtl* ctl, int parity, hipStream_t stream);
+size_t bounds_tile_queue_scratch_floats(int max_groups);
 // bounds of the 8 children of the *d_groups expansions in `parents` (count known to the device only); max_groups sizes the grids
 // (d_chunks: QCtl::chunks -- the evaluation leaves chunk partials in `scratch` when it splits the cloud, and says so there)
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,

@@ -493,6 +493,8 @@ void Engine::release()
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
 	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
+	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
+	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
 	hipFree(d_qinit_); hipHostFree(h_qinit_); d_qinit_ = nullptr; h_qinit_ = nullptr;
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
@@ -971,6 +973,8 @@ void Engine::ensure_queues(size_t nsearch)
 	HIPCHK(hipStreamSynchronize(stream_));
 	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_);
+	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
+	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
 	const size_t max_groups = cap * kQueueMaxPop;
@@ -981,6 +985,16 @@ void Engine::ensure_queues(size_t nsearch)
 	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups)));
+	if (tiles_usable()) {
+		// the second expansion list of a round (LDS-staged DT tiles): same capacity as the direct list
+		for (int k = 0; k < 2; k++) {
+			HIPCHK(hipMalloc(&qtile_.parents[k], sizeof(ParentRec) * max_groups));
+			HIPCHK(hipMalloc(&qtile_.segs[k], sizeof(TileSeg) * 2 * cap));
+		}
+		HIPCHK(hipMalloc(&qtile_.ub, sizeof(float) * max_groups * kGroup));
+		HIPCHK(hipMalloc(&qtile_.lb, sizeof(float) * max_groups * kGroup));
+		HIPCHK(hipMalloc(&qtile_.scratch, sizeof(float) * bounds_tile_queue_scratch_floats((int)(2 * cap))));
+	}
 	if (!d_qctl_) {
 		HIPCHK(hipMalloc(&d_qctl_, sizeof(QCtl)));
 		HIPCHK(hipHostMalloc(&h_qctl_, sizeof(QCtl)));
@@ -1010,14 +1024,20 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	qp.K = K;
 	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
 	int parity = 0, chunk = 3;
+	// the tile list: always on (lds_tiles 1), or -- the default -- only for the rounds that follow a read-back in which searches
+	// qualified (QCtl::tile_hint moved): shallow batches, i.e. every default registration, never pay for the extra launch
+	const bool tiles = qtile_.ub != nullptr;
+	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
+	tile_hint_seen_ = 0;
 	while (true) {
 		const double t0 = now_ms();
 		int last = 0;
 		const int max_groups = (int)(S * (size_t)qp.K);
 		for (int r = 0; r < chunk; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_));
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
 			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+			if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
 			last = parity;
 			parity ^= 1;
 			cnt_.bounds_launches++;
@@ -1029,16 +1049,18 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		HIPCHK(hipStreamSynchronize(stream_));
 		t_wait_ += now_ms() - t1;
 		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-		if (h_qctl_->n_groups[last] == 0 || cancel_.load()) break;
+		if ((h_qctl_->n_groups[last] == 0 && h_qctl_->n_tile_groups[last] == 0) || cancel_.load()) break;
 		chunk = 4;
+		if (tiles && p_.lds_tiles == 2) { qp.tile_on = h_qctl_->tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = h_qctl_->tile_hint; }
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)
 		if (p_.adaptive_k && K >= 32) {
-			const int active_est = (h_qctl_->n_groups[last] + qp.K - 1) / qp.K;       // searches that filled their quota
+			const int active_est = (h_qctl_->n_groups[last] + h_qctl_->n_tile_groups[last] + qp.K - 1) / qp.K;       // searches that filled their quota
 			qp.K = active_est <= 16 ? kQueueMaxPop : (active_est <= 64 ? std::min(kQueueMaxPop, 2 * K) : K);
 		}
 	}
+	cnt_.tile_expansions += h_qctl_->tile_total;
 	const double t2 = now_ms();
 	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
@@ -1411,9 +1433,17 @@ void Engine::flow_reset()
 	if (d_qsearch_) HIPCHK(hipMemsetAsync(d_qsearch_, 0, sizeof(QSearch) * cap_qsearch_, stream_));
 }
 
+bool Engine::tiles_usable() const
+{
+	// the tile kernel stages 4x4x4 fp32 bricks and sums every point (no trimming)
+	return p_.lds_tiles != 0 && dt_.layout == 1 && !p_.bounds_fp16 && inliers_ >= (int)N_;
+}
+
 QParams Engine::queue_params() const
 {
 	QParams qp{};
+	qp.tile_on = 0; qp.tile_min = std::max(8, p_.tile_min);
+	qp.tile_spread = tiles_usable() ? (float)((double)p_.tile_spread_vox / dt_.scale) : 0.f;
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;

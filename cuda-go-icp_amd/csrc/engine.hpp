@@ -35,6 +35,10 @@ struct Params {
 	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 128 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
+	int lds_tiles = 2;            // LDS-staged DT tiles for inner searches whose selected nodes lie within a few voxels of each other (deep rounds): 0 off, 1 the
+	                              // tile evaluation is launched every round, 2 only while the previous rounds had searches that qualify (default)
+	float tile_spread_vox = 10.f; // ... "a few": largest extent of a search's selected translations, in DT voxels (measured: the tile kernel is 1.7x the gathering one at 3 voxels, 1.3x at 5, even at 10)
+	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 	// Search domain ([params.rotation] / [params.translation] of the reference's configs, test/skull_goicp.toml:22-41;
@@ -50,6 +54,7 @@ struct Counters {
 	long long rot_pops = 0, trans_pops = 0, cubes = 0, inner_calls = 0, icp_runs = 0, icp_iters = 0;
 	long long bounds_launches = 0;
 	long long queue_fallbacks = 0;
+	long long tile_expansions = 0;   // BnB expansions evaluated from LDS-staged DT tiles (8 cube bounds each; counted in `cubes` too)
 };
 
 // what the viewer polls (fgoicp.hpp:34,67-69; goicp_kernel.cu:161-177)
@@ -233,6 +238,10 @@ private:
 	ParentRec* d_qparents_[2] = {nullptr, nullptr};
 	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
 	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;
+	QTile qtile_{};                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
+	bool tiles_usable() const;
+	int tile_hint_seen_ = 0;              // QCtl::tile_hint at the last read-back
+	long long tile_rounds_ = 0;           // rounds whose tile evaluation was launched
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging
 	float* d_icp_partials_ = nullptr; IcpState* d_icp_state_ = nullptr; IcpState* h_icp_state_ = nullptr;

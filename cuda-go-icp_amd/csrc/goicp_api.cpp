@@ -49,6 +49,7 @@ void fill_counters(goicp_counters* o, const goicp::Counters& c)
 {
 	o->rot_pops = c.rot_pops; o->trans_pops = c.trans_pops; o->cubes = c.cubes; o->inner_calls = c.inner_calls;
 	o->icp_runs = c.icp_runs; o->icp_iters = c.icp_iters; o->bounds_launches = c.bounds_launches; o->queue_fallbacks = c.queue_fallbacks;
+	o->tile_expansions = c.tile_expansions;
 }
 
 void fill_result(goicp_result* out, const goicp::Result& r)
@@ -102,6 +103,7 @@ void goicp_params_default(goicp_params* p)
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
 	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->icp_nn_cache = d.icp_nn_cache; p->flow = d.flow; p->adaptive_k = d.adaptive_k; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
+	p->lds_tiles = d.lds_tiles; p->tile_spread_vox = d.tile_spread_vox; p->tile_min = d.tile_min;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -145,6 +147,9 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
 			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.icp_nn_cache = params->icp_nn_cache; p.flow = params->flow; p.adaptive_k = params->adaptive_k; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
+			p.lds_tiles = params->lds_tiles;
+			if (params->tile_spread_vox > 0.f) p.tile_spread_vox = params->tile_spread_vox;
+			if (params->tile_min > 0) p.tile_min = params->tile_min;
 		}
 		goicp_engine* h = new goicp_engine{nullptr};
 		try { h->e = new goicp::Engine(p, target_xyz, n_target, source_xyz, n_source); }

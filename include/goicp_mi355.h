@@ -137,6 +137,14 @@ typedef struct goicp_params {
 	int32_t device_queues;   /* 1 (default): the inner-BnB translation queues live on the device -- a round of all active inner
 	                          * searches is two launches, no host round trip; 0: host-side queues (always used with trans_batch == 1,
 	                          * the reference visit order) */
+	int32_t lds_tiles;       /* LDS-staged distance-transform tiles (north_star (a)) for the device-queue search: an inner search whose
+	                          * selected nodes lie within tile_spread_vox voxels of each other (the deep rounds of a search) has them
+	                          * evaluated by bounds_tile_kernel -- the DT box a 64-point patch of the cloud can reach under ALL of them is
+	                          * staged in LDS once, a lookup is a ds_read -- instead of by the gathering kernel; same per-point float
+	                          * expressions (bounds agree to the order of the sums).  2 (default): that evaluation is launched only while the
+	                          * previous rounds had searches that qualify (shallow registrations never pay for it); 1: every round; 0: off */
+	float tile_spread_vox;   /* default 10 */
+	int32_t tile_min;        /* fewest expansions of a search for the tile list (default and minimum 8) */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);
@@ -205,6 +213,7 @@ int goicp_eval_sse(goicp_handle h, const float R[9], const float t[3], float* ss
 typedef struct goicp_counters {
 	int64_t rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters, bounds_launches;
 	int64_t queue_fallbacks;     /* batches of inner searches re-run through the host queues because a device queue outgrew its slab */
+	int64_t tile_expansions;     /* BnB expansions (8 cube bounds each, counted in `cubes` too) evaluated from LDS-staged DT tiles */
 } goicp_counters;
 int goicp_inner_bnb(goicp_handle h, const float R[9], int32_t level, float incumbent, float* value,
                     float best_node[4], goicp_counters* counters);

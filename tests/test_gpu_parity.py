@@ -1269,12 +1269,12 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
 
 
 def test_lds_tile_kernel_matches_direct_kernel(pkg, bunny_model, bunny_data):
-    """north_star (a) names LDS-staged DT tiles; bounds_tile_kernel is that design for the deep expansions of one search (a
-    lane = one expansion, the DT box a 64-point patch can reach is copied to LDS once; lookups outside the box or the grid
-    read global memory).  It is a measurement vehicle (tools/tile_probe.py, DESIGN 3.6: 1.2x at best), not on the search
-    path; this test keeps it honest: same per-point arithmetic as the direct kernel, so the bounds agree to summation
-    order, for deep blocks (everything staged), shallow ones (nothing fits: every lookup takes the fallback) and ragged
-    segment sizes."""
+    """north_star (a) names LDS-staged DT tiles; bounds_tile_kernel is that design for the expansions of one search whose
+    translations lie close together (a lane group = one expansion, the DT box a 64-point patch can reach under all of them is
+    copied to LDS once; a patch whose box does not fit takes the gathering kernel's sibling path).  The search lists such
+    expansions for it (test_lds_tiles_on_the_search_path); this test pins the kernel itself: same per-point arithmetic as
+    the direct kernel, so the bounds agree to summation order, for deep blocks (everything staged), shallow ones (nothing
+    fits) and ragged segment sizes (1, 17 expansions: several lanes per expansion)."""
     import ctypes as C
     from cuda_go_icp_amd import binding as B
     reg = pkg.Registration(bunny_model, bunny_data, 1e-3)
@@ -1305,6 +1305,33 @@ def test_lds_tile_kernel_matches_direct_kernel(pkg, bunny_model, bunny_data):
     ub, lb = reg.eval_bounds(rots[:9].reshape(3, 3), np.array([[par[0, 0, 0] + par[0, 0, 3] / 4, par[0, 0, 1] + par[0, 0, 3] / 4, par[0, 0, 2] + par[0, 0, 3] / 4, par[0, 0, 3] / 2]], np.float32), 5)
     assert abs(ub[0] - out[2][0]) <= 1e-6 * max(abs(ub[0]), 1e-3) and abs(lb[0] - out[3][0]) <= 1e-6 * max(abs(lb[0]), 1e-3)
     reg.close()
+
+
+def test_lds_tiles_on_the_search_path(pkg, bunny_model, bunny_data10):
+    """The tile list of the device-queue search (Params::lds_tiles): a registration that has to dig -- threshold below the
+    optimum's error, so the search proves the optimum and its inner searches reach sub-voxel cubes -- run with the tile
+    list off, always on, and in the default auto mode.  The tile evaluation uses the same per-point float expressions, so
+    the search takes the same decisions: same optimum, node and cube counts within 0.1 %; with the list on a share of the
+    cube bounds really comes from LDS tiles; a default (shallow) registration lists nothing there."""
+    runs = {}
+    for tiles in (0, 1, 2):
+        eng = pkg.FastGoICP(bunny_model, bunny_data10, 1e-4, lds_tiles=tiles, tile_spread_vox=16.0)
+        eng.run()
+        c = eng.counters
+        runs[tiles] = (float(eng.get_best_error()), eng.optR.copy(), int(c.cubes), int(c.rot_pops), int(c.tile_expansions))
+        eng.registration.close()
+    sse0, R0, cubes0, rot0, t0 = runs[0]
+    assert t0 == 0
+    for tiles in (1, 2):
+        sse, R, cubes, rot, te = runs[tiles]
+        assert abs(sse - sse0) <= 1e-5 * sse0 and rot_angle(R, R0) <= 1e-5
+        assert abs(cubes - cubes0) <= 1e-3 * cubes0 and abs(rot - rot0) <= max(1, 1e-3 * rot0)
+    assert runs[1][4] * 8 > 0.005 * runs[1][2]                # always on: a visible share (measured ~1 % on this run, 64-80 % on the full bunny at mse 3e-5)
+    assert 0 < runs[2][4] <= runs[1][4]                       # auto: launched only after a read-back saw searches that qualify
+    shallow = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3)
+    shallow.run()
+    assert shallow.counters.tile_expansions == 0
+    shallow.registration.close()
 
 
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):

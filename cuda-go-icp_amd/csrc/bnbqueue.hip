@@ -142,6 +142,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		for (int w2 = 1; w2 < kQThreads / 64; w2++)
 			if (sh.red_ub[w2] < mub || (sh.red_ub[w2] == mub && sh.red_idx[w2] < midx)) { mub = sh.red_ub[w2]; midx = sh.red_idx[w2]; }
 		const bool improved = mub < best;
+		if (tid == 0 && mub < S->min_ub) S->min_ub = mub;
 		if (improved) best = mub;
 		if (improved && tid == midx) { S->bx = cx; S->by = cy; S->bz = cz; S->bw = cw; S->improved = 1; }
 		// push the children that can still improve on the incumbent (:327-335), unless the depth limit says leaf
@@ -466,7 +467,7 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241
 	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY;
 }
 
 // the listed slots become fresh searches (continuous flow: slots are recycled while other searches keep running)
@@ -479,7 +480,7 @@ __global__ void bnb_init_list_kernel(QSearch* __restrict__ searches, QNode* __re
 	QSearch& S = searches[in.slot];
 	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot;
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY;
 }
 
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream)

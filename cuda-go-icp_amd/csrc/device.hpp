@@ -93,7 +93,8 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 	int32_t n_parents, parent_off;  // this round's expansions in the round's list
 	int32_t pops, cubes;            // tNodeCount of this search / children evaluated
 	float bx, by, bz, bw;           // best child (corner, width), valid when improved
-	int32_t tile, pad;              // this round's expansions are in the tile list (parent_off counts in that list)
+	int32_t tile;                   // this round's expansions are in the tile list (parent_off counts in that list)
+	float min_ub;                   // smallest upper bound of any child this search evaluated (whether or not it beat the incumbent)
 };
 struct TileSeg { int32_t off, n, rot; };   // tile list: a search's expansions parents[off .. off+n), n <= 64, one rotation
 struct QCtl {

@@ -98,6 +98,7 @@ struct Engine::InnerSearch {
 	std::priority_queue<Node> pq;
 	std::vector<Node> parents;    // popped this round
 	long long pops = 0, cubes = 0;
+	float min_ub = std::numeric_limits<float>::infinity();   // smallest upper bound of any cube evaluated
 };
 
 float Engine::rot_coeff(int level) const
@@ -1069,7 +1070,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		InnerSearch& s = *searches[i];
 		s.best = q.best; s.improved = q.improved != 0; s.done = true;
 		s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
-		s.pops = q.pops; s.cubes = q.cubes;
+		s.pops = q.pops; s.cubes = q.cubes; s.min_ub = q.min_ub;
 	}
 	t_collect_ += now_ms() - t2;
 	return true;
@@ -1159,6 +1160,7 @@ void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vect
 					const float ub = st.h_ub[o], lb = st.h_ub[st.B + o];
 					s->cubes++;
 					if (trans_boxed_ && !in_box(c, trans_lo_, trans_hi_)) continue;   // outside the configured translation range
+					if (ub < s->min_ub) s->min_ub = ub;
 					if (ub < s->best) { s->best = ub; s->best_node = c; s->improved = true; }   // :319-324
 					if (lb >= s->best) continue;                                                  // :327
 					if (p_.trans_search_depth > 0 && !(std::ldexp(c.w, p_.trans_search_depth) > trans_root_.w)) continue;   // depth limit reached: evaluated, not expanded
@@ -1332,6 +1334,10 @@ bool Engine::handle_ub(Kid& k, const SearchOut& s)
 {
 	cnt_.trans_pops += s.pops; cnt_.cubes += s.cubes; cnt_.inner_calls++;
 	k.node.ub = s.best;
+	// the widened search orders rotation cubes of equal lower bound (all the shallow ones: lb = 0) by the smallest upper bound
+	// their own upper-bound search saw -- the basin most likely to refine the optimum is expanded first.  The reference leaves
+	// that order to its heap (any order of a best-first BnB is valid); the reference-order mode keeps the key at 0.
+	k.node.tie = (p_.wide_children && p_.ub_tiebreak && std::isfinite(s.min_ub)) ? s.min_ub : 0.f;
 	std::memcpy(curR_, k.R, sizeof(curR_));
 	if (s.improved) { curT_[0] = s.best_node.x + s.best_node.w / 2; curT_[1] = s.best_node.y + s.best_node.w / 2; curT_[2] = s.best_node.z + s.best_node.w / 2; }
 	if (!(s.best < opt_err_) || !s.improved) return false;
@@ -1378,7 +1384,7 @@ void Engine::process_parents(const std::vector<Node>& parents)
 		s.pq.push(troot);
 		return s;
 	};
-	auto out = [](const InnerSearch& s) { return SearchOut{s.best, s.improved, s.best_node, s.pops, s.cubes}; };
+	auto out = [](const InnerSearch& s) { return SearchOut{s.best, s.improved, s.best_node, s.pops, s.cubes, s.min_ub}; };
 
 	if (p_.wide_children) {
 		// every child's upper-bound AND lower-bound search in lock-step: one launch per round covers
@@ -1467,8 +1473,8 @@ void Engine::flow_fallback()
 		u.pq.push(trans_root_); l.pq.push(trans_root_);
 		std::vector<InnerSearch*> ptr{&u, &l};
 		run_inner_host(ptr, rots);
-		if (handle_ub(f.kid, SearchOut{u.best, u.improved, u.best_node, u.pops, u.cubes})) return;
-		handle_lb(f.kid, SearchOut{l.best, l.improved, l.best_node, l.pops, l.cubes});
+		if (handle_ub(f.kid, SearchOut{u.best, u.improved, u.best_node, u.pops, u.cubes, u.min_ub})) return;
+		handle_lb(f.kid, SearchOut{l.best, l.improved, l.best_node, l.pops, l.cubes, l.min_ub});
 	}
 }
 
@@ -1563,8 +1569,8 @@ int Engine::flow_step(int max_rot_pops)
 			f.handled = true;
 			free_search_.push_back(f.s_ub); free_search_.push_back(f.s_lb); free_rot_.push_back(f.rot_slot);
 			if (stop) continue;                                                  // early exit taken: the rest is abandoned
-			const SearchOut su{u.best, u.improved != 0, Node{u.bx, u.by, u.bz, u.bw, 0.f, 0.f, 0}, u.pops, u.cubes};
-			const SearchOut sl{l.best, l.improved != 0, Node{l.bx, l.by, l.bz, l.bw, 0.f, 0.f, 0}, l.pops, l.cubes};
+			const SearchOut su{u.best, u.improved != 0, Node{u.bx, u.by, u.bz, u.bw, 0.f, 0.f, 0}, u.pops, u.cubes, u.min_ub};
+			const SearchOut sl{l.best, l.improved != 0, Node{l.bx, l.by, l.bz, l.bw, 0.f, 0.f, 0}, l.pops, l.cubes, l.min_ub};
 			if (handle_ub(f.kid, su)) { stop = true; continue; }
 			handle_lb(f.kid, sl);
 		}
@@ -1608,6 +1614,21 @@ StepStatus Engine::register_step(int max_rot_pops)
 			parents.push_back(parent);
 		}
 		if (parents.empty()) break;
+		// ub_share: part of a batch goes to the queued cubes with the smallest upper bound seen inside them, whatever their lower
+		// bound -- the early exit (jly_goicp.cpp:527) needs a pose below SSEThresh, and that is found by refining a promising
+		// basin, not by closing the gap.  Valid: any expansion order keeps the bounds; the batch's first parents are still the
+		// smallest lower bounds, so the stop rule (:416) sees the same frontier.
+		if (p_.wide_children && p_.ub_share > 0.f && !converged_ && queue_.size() > 1 && pops < max_rot_pops) {
+			size_t want = std::min<size_t>({(size_t)((float)P * p_.ub_share), queue_.size(), (size_t)(max_rot_pops - pops)});
+			if (want > 0) {
+				std::vector<Node> rest;
+				rest.reserve(queue_.size());
+				while (!queue_.empty()) { rest.push_back(queue_.top()); queue_.pop(); }
+				std::partial_sort(rest.begin(), rest.begin() + (long)want, rest.end(), [](const Node& a, const Node& b) { return a.tie < b.tie; });
+				for (size_t i = 0; i < want; i++) { parents.push_back(rest[i]); cnt_.rot_pops++; pops++; }
+				for (size_t i = want; i < rest.size(); i++) queue_.push(rest[i]);
+			}
+		}
 		process_parents(parents);
 		publish(false);
 	}
@@ -1637,7 +1658,7 @@ int Engine::donate(int max_nodes, float* out)
 		if ((i & 1) && n < max_nodes) {
 			const Node& c = all[i];
 			float* o = out + 7 * n++;
-			o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = c.ub; o[5] = c.lb; o[6] = (float)c.l;
+			o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = c.tie; o[5] = c.lb; o[6] = (float)c.l;
 		} else queue_.push(all[i]);
 	}
 	return n;
@@ -1648,6 +1669,7 @@ void Engine::receive(const float* in, int n)
 	for (int i = 0; i < n; i++) {
 		const float* o = in + 7 * i;
 		Node c{o[0], o[1], o[2], o[3], o[4], o[5], (int)o[6]};
+		c.tie = o[4];                       // the ub slot of a travelling cube carries its tie-break key
 		if (c.lb < opt_err_) queue_.push(c);
 	}
 	if (!queue_.empty() && !early_exit_) converged_ = false;

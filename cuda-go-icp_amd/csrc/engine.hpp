@@ -35,6 +35,11 @@ struct Params {
 	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 128 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
+	int ub_tiebreak = 0;          // opt-in, widened search only: rotation cubes with EQUAL lower bounds and equal width are expanded in the order of the smallest
+	                              // upper bound their own inner search saw -- the reference leaves that order to its heap; 0: as the reference.  Measured (round 3,
+	                              // DESIGN 4): ties are rare beyond level 2, no registration got faster -- default off
+	float ub_share = 0.f;         // opt-in, widened search: on top of a batch's parents by smallest lower bound, this fraction more are drawn by the smallest upper
+	                              // bound seen inside them (needs ub_tiebreak = 1 for the key).  Measured slower everywhere: default 0
 	int lds_tiles = 2;            // LDS-staged DT tiles for inner searches whose selected nodes lie within a few voxels of each other (deep rounds): 0 off, 1 the
 	                              // tile evaluation is launched every round, 2 only while the previous rounds had searches that qualify (default)
 	float tile_spread_vox = 10.f; // ... "a few": largest extent of a search's selected translations, in DT voxels (measured: the tile kernel is 1.7x the gathering one at 3 voxels, 1.3x at 5, even at 10)
@@ -70,10 +75,12 @@ struct Result {
 struct Node {
 	float x, y, z, w, ub, lb;
 	int l;
+	float tie = 0.f;     // third key of the ROTATION queue in the widened search: the smallest upper bound seen inside the cube (0 = unused)
 	friend bool operator<(const Node& a, const Node& b)
 	{
-		if (a.lb != b.lb) return a.lb > b.lb;
-		return a.w < b.w;
+		if (a.lb != b.lb) return a.lb > b.lb;      // smaller lower bound first, then the wider cube (jly_goicp.h:44-72)
+		if (a.w != b.w) return a.w < b.w;
+		return a.tie > b.tie;                      // equal in the reference's order (there the heap decides): the more promising cube first
 	}
 };
 
@@ -157,7 +164,7 @@ private:
 	void ensure_queues(size_t nsearch);
 	void process_parents(const std::vector<Node>& parents);
 	struct Kid { Node node; float R[9]; float parent_lb; };                       // a rotation child and its Rodrigues matrix
-	struct SearchOut { float best; bool improved; Node best_node; long long pops, cubes; };   // what an inner search returns
+	struct SearchOut { float best; bool improved; Node best_node; long long pops, cubes; float min_ub; };   // what an inner search returns (min_ub: smallest upper bound of any cube it evaluated)
 	void make_kids(const std::vector<Node>& parents, std::vector<Kid>& kids);
 	bool handle_ub(Kid& k, const SearchOut& s);
 	void handle_lb(Kid& k, const SearchOut& s);

@@ -145,6 +145,12 @@ typedef struct goicp_params {
 	                          * previous rounds had searches that qualify (shallow registrations never pay for it); 1: every round; 0: off */
 	float tile_spread_vox;   /* default 10 */
 	int32_t tile_min;        /* fewest expansions of a search for the tile list (default and minimum 8) */
+	int32_t ub_tiebreak;     /* opt-in (default 0: measured, no registration got faster -- ties are rare beyond level 2).  1 (widened search only): rotation cubes of EQUAL lower bound and width are
+	                          * expanded in the order of the smallest upper bound their own inner search saw (the basin most likely to refine the
+	                          * optimum first).  The reference leaves that order to its heap (src/goicp/jly_goicp.h:44-56); any order of a best-first
+	                          * BnB keeps the bounds valid.  0: the reference's key only.  Ignored in the reference-order mode */
+	float ub_share;          /* widened search: on top of the rot_batch parents drawn by smallest lower bound, this fraction more are drawn per batch by the
+	                          * smallest upper bound seen inside them (needs ub_tiebreak = 1; default 0 = none: measured slower) */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);

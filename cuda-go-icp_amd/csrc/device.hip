@@ -1082,7 +1082,30 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 		row_take(key[0], l, row, node[1]);
 		fb = load_child_boxes4(kd.boxes[1] + (size_t)node[1] * 384, l);
 	}
-	RowNn r{nn_upper_bound<LAYOUT>(dt, qx, qy, qz), INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
+	RowNn r{0.f, INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
+	if (!TWO && dt.nn_ids) {
+		// the walk starts from a REAL candidate: a target point whose seed voxel is nearest to the query's voxel (clamped into
+		// the grid) -- nearly always the neighbour itself, so every box beyond the true distance is pruned from the first step
+		// (the distance-transform bound below carries up to 1.8 voxels of slack: far from the surface that is a shell with
+		// dozens of leaves in it, and the pass lasts as long as its longest walk).  Any target point is a valid candidate, so
+		// exactness does not depend on the table; lane 0 of the row holds it until a scan finds a nearer one (or an equally
+		// near one with a lower index).
+		const int V1 = dt.V - 1;
+		const int ix = min(max((int)rintf((qx - dt.xmin_f) * dt.scale_f), 0), V1);
+		const int iy = min(max((int)rintf((qy - dt.ymin_f) * dt.scale_f), 0), V1);
+		const int iz = min(max((int)rintf((qz - dt.zmin_f) * dt.scale_f), 0), V1);
+		size_t off;
+		if (LAYOUT == 0) off = ((size_t)iz * dt.V + iy) * dt.V + ix;
+		else off = (((size_t)(iz >> 2) * dt.VB + (iy >> 2)) * dt.VB + (ix >> 2)) * 64 + (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3));
+		const int slot = dt.nn_ids[off];
+		const float4 pt = kd.pts[slot];
+		const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
+		float e = d0 * d0;                                                 // the leaf scan's accumulation order: the same bits
+		e += d1 * d1;
+		e += d2 * d2;
+		r.best = e; r.idx = __float_as_int(pt.w); r.mine = l == 0; r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = slot;
+	} else
+		r.best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
 	unsigned bbits = __float_as_uint(r.best);
 	unsigned b2bits = 0x7f800000u;                // +inf: nothing but the neighbour seen yet
 	int d = 0;
@@ -2182,6 +2205,75 @@ __global__ void dt_finish_kernel(const int32_t* w, DtDesc dt, float* out)
 		size_t b = ((size_t)(z >> 2) * dt.VB + (y >> 2)) * dt.VB + (x >> 2);
 		out[b * 64 + (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))] = v;
 	}
+}
+
+// ---- nearest-target-point table: the EDT passes again, carrying which seed attains the minimum ----
+__global__ void nnseed_fill_kernel(int32_t* __restrict__ w, int32_t* __restrict__ id, size_t n)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (; i < n; i += (size_t)gridDim.x * blockDim.x) { w[i] = kEdtInf; id[i] = 0x7fffffff; }
+}
+__global__ void nnseed_seed_kernel(const float4* __restrict__ pts, int nslots, DtDesc dt, int32_t* __restrict__ w, int32_t* __restrict__ id)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= nslots) return;
+	const float4 p = pts[s];
+	if (!(p.x < INFINITY)) return;                                            // padding slot
+	const int x = (int)(((double)p.x - dt.xmin) * dt.scale + 0.5);          // the seeding rule of the distance transform (dt_seed_kernel)
+	const int y = (int)(((double)p.y - dt.ymin) * dt.scale + 0.5);
+	const int z = (int)(((double)p.z - dt.zmin) * dt.scale + 0.5);
+	const int V = dt.V;
+	if (x < 0 || x >= V || y < 0 || y >= V || z < 0 || z >= V) return;
+	const size_t v = ((size_t)z * V + y) * V + x;
+	w[v] = 0;
+	atomicMin(&id[v], s);                                                     // lowest slot: the table is reproducible
+}
+__global__ __launch_bounds__(256) void nnseed_pass_kernel(int32_t* __restrict__ w, int32_t* __restrict__ id, int V, int axis)
+{
+	extern __shared__ int32_t row[];                                          // [V] distances, [V] ids
+	int32_t* idrow = row + V;
+	const int r = blockIdx.x;
+	size_t base, stride;
+	if (axis == 0) { base = (size_t)r * V; stride = 1; }
+	else if (axis == 1) { int z = r / V, x = r - z * V; base = (size_t)z * V * V + x; stride = V; }
+	else { base = r; stride = (size_t)V * V; }
+	for (int i = threadIdx.x; i < V; i += blockDim.x) { row[i] = w[base + i * stride]; idrow[i] = id[base + i * stride]; }
+	__syncthreads();
+	for (int x = threadIdx.x; x < V; x += blockDim.x) {
+		int best = kEdtInf, bi = x;
+		for (int i = 0; i < V; i++) {
+			const int d = x - i;
+			const int v = d * d + row[i];
+			if (v < best) { best = v; bi = i; }
+		}
+		w[base + x * stride] = best;
+		id[base + x * stride] = idrow[bi];
+	}
+}
+template <int LAYOUT>
+__global__ void nnseed_finish_kernel(const int32_t* __restrict__ id, DtDesc dt, int32_t* __restrict__ out)
+{
+	const int V = dt.V;
+	const size_t n = (size_t)V * V * V;
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (LAYOUT == 0) { out[i] = id[i]; return; }
+	const int x = (int)(i % V), y = (int)((i / V) % V), z = (int)(i / ((size_t)V * V));
+	const size_t b = ((size_t)(z >> 2) * dt.VB + (y >> 2)) * dt.VB + (x >> 2);
+	out[b * 64 + (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))] = id[i];
+}
+hipError_t launch_nn_seed_build(const float4* pts, int nslots, const DtDesc& dt, int32_t* work_d, int32_t* work_id, int32_t* out, hipStream_t stream)
+{
+	const int V = dt.V;
+	const size_t n = (size_t)V * V * V;
+	hipLaunchKernelGGL(nnseed_fill_kernel, dim3(4096), dim3(256), 0, stream, work_d, work_id, n);
+	hipLaunchKernelGGL(nnseed_seed_kernel, dim3((nslots + 255) / 256), dim3(256), 0, stream, pts, nslots, dt, work_d, work_id);
+	for (int axis = 0; axis < 3; axis++)
+		hipLaunchKernelGGL(nnseed_pass_kernel, dim3(V * V), dim3(256), 2 * V * sizeof(int32_t), stream, work_d, work_id, V, axis);
+	const dim3 grid((unsigned)((n + 255) / 256));
+	if (dt.layout == 0) hipLaunchKernelGGL(nnseed_finish_kernel<0>, grid, dim3(256), 0, stream, work_id, dt, out);
+	else hipLaunchKernelGGL(nnseed_finish_kernel<1>, grid, dim3(256), 0, stream, work_id, dt, out);
+	return hipGetLastError();
 }
 
 // half-precision copy of a bricked grid, rounded toward zero (|half| <= |float|: lower bounds stay valid)

@@ -24,6 +24,10 @@ struct DtDesc {
 	float c1, c2;   // |F_float - F_exact| <= c1 + c2*|F|
 	const double* overshoot;   // [n_overshoot]: (double)sqrtf(s)/scale for the out-of-grid extension (jly_3ddt.cpp:1025)
 	int n_overshoot;
+	// nearest-target-point table (ICP only; null = absent): per voxel, in the grid's layout, the leaf slot (KdDesc::pts) of a
+	// target point whose seed voxel is nearest to this voxel -- a REAL candidate for the neighbour search of any query that
+	// falls into the voxel, i.e. an upper bound that is almost always the answer itself (launch_nn_seed_build)
+	const int32_t* nn_ids;
 };
 
 // One translation sub-cube to bound (the inner body of GoICP::InnerBnB, jly_goicp.cpp:262-315).
@@ -205,5 +209,8 @@ hipError_t launch_kd_build(const float* d_xyz, int M, int K, const float mn[3], 
 hipError_t launch_dt_build(const float* model_xyz, int M, const DtDesc& dt, int32_t* work, float* out,
                            hipStream_t stream);
 hipError_t launch_dt_to_half(const float* bricked, void* out_half, size_t n, hipStream_t stream);
+// nearest-target-point table: the same exact EDT passes, carrying the arg-min.  pts: the k-d tree's leaf slots (padding slots
+// have infinite coordinates); work_d / work_id: V^3 int32 each (linear); out: ids in dt.layout (V^3, or VB^3 x 64 bricked)
+hipError_t launch_nn_seed_build(const float4* pts, int nslots, const DtDesc& dt, int32_t* work_d, int32_t* work_id, int32_t* out, hipStream_t stream);
 
 }  // namespace goicp

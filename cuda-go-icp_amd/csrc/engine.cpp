@@ -387,6 +387,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			HIPCHK(hipMalloc(&d_kd_pts_, sizeof(float4) * kh.pts.size()));
 			HIPCHK(hipMemcpy(d_kd_pts_, kh.pts.data(), sizeof(float4) * kh.pts.size(), hipMemcpyHostToDevice));
 			kd_.K = kh.K;
+			kd_slots_ = kh.pts.size();
 		} else {
 			// device build: Morton sort + bottom-up boxes, no host tree
 			int K = 1;
@@ -403,11 +404,26 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			const float ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]});
 			HIPCHK(launch_kd_build(d_model, (int)M_, K, mn, ext, d_kd_boxes_, d_kd_pts_, stream_));
 			kd_.K = K;
+			kd_slots_ = (size_t)kLeafSlots * ((size_t)1 << (6 * K));
 		}
 		for (int l = 0; l < kMaxLevels; l++) kd_.boxes[l] = d_kd_boxes_[l];
 		kd_.pts = d_kd_pts_; kd_.M = (int)M_;
 	}
 	lap("k-d hierarchy + upload");
+	if (p_.icp_point_seed) {
+		// nearest-target-point table: per voxel the leaf slot of a target point whose seed voxel is nearest (the exact EDT passes
+		// again, carrying their arg-min) -- the neighbour search of the ICP starts from that point instead of from a bound
+		const size_t V = dt_.V, nlin = V * V * V;
+		const size_t nout = dt_.layout ? (size_t)dt_.VB * dt_.VB * dt_.VB * 64 : nlin;
+		const int nslots = (int)kd_slots_;                  // the slots that exist (the root group of the hierarchy is sparse: 16 x 2^D, not 16 x 64^K)
+		DevBuf<int32_t> wd(nlin), wi(nlin);
+		HIPCHK(hipMalloc(&d_nn_ids_, sizeof(int32_t) * nout));
+		HIPCHK(hipMemsetAsync(d_nn_ids_, 0, sizeof(int32_t) * nout, stream_));          // brick padding beyond V: slot 0, never addressed
+		HIPCHK(launch_nn_seed_build(d_kd_pts_, nslots, dt_, wd.p, wi.p, d_nn_ids_, stream_));
+		HIPCHK(hipStreamSynchronize(stream_));
+		dt_.nn_ids = d_nn_ids_;
+		lap("nearest-point table");
+	}
 	HIPCHK(hipMalloc(&d_icp_partials_, sizeof(float) * std::max(icp_partials_floats((int)N_), (size_t)icp_trim_blocks((int)N_) * kIcpAcc)));
 	if (inliers_ < (int)N_) {
 		HIPCHK(hipMalloc(&d_nn_d2_, sizeof(float) * N_));
@@ -500,6 +516,7 @@ void Engine::release()
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_); hipFree(d_dt16_); d_dt16_ = nullptr;
+	hipFree(d_nn_ids_); d_nn_ids_ = nullptr;
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);

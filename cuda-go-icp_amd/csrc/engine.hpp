@@ -35,6 +35,8 @@ struct Params {
 	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 128 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
+	int icp_point_seed = 1;       // 1: the ICP neighbour search starts every walk from a real candidate read from a per-voxel nearest-target-point table
+	                              // (built once with the k-d tree: the EDT passes carrying their arg-min; V^3 x 4 bytes); 0: from the distance-transform bound
 	int ub_tiebreak = 0;          // opt-in, widened search only: rotation cubes with EQUAL lower bounds and equal width are expanded in the order of the smallest
 	                              // upper bound their own inner search saw -- the reference leaves that order to its heap; 0: as the reference.  Measured (round 3,
 	                              // DESIGN 4): ties are rare beyond level 2, no registration got faster -- default off
@@ -221,6 +223,8 @@ private:
 	float* d_dt_ = nullptr;
 	DtDesc dt16_{};                   // Params::bounds_fp16: the same grid in half precision (layout 2)
 	void* d_dt16_ = nullptr;
+	size_t kd_slots_ = 0;                 // float4 slots behind KdDesc::pts
+	int32_t* d_nn_ids_ = nullptr;         // nearest-target-point table of the ICP neighbour search (DtDesc::nn_ids)
 	bool score_exact_ = false;        // set while eval_sse scores a pose: always the fp32 grid
 	const DtDesc& bounds_dt() const { return (d_dt16_ && !score_exact_ && inliers_ >= (int)N_) ? dt16_ : dt_; }
 	double* d_overshoot_ = nullptr;

@@ -149,6 +149,11 @@ typedef struct goicp_params {
 	                          * expanded in the order of the smallest upper bound their own inner search saw (the basin most likely to refine the
 	                          * optimum first).  The reference leaves that order to its heap (src/goicp/jly_goicp.h:44-56); any order of a best-first
 	                          * BnB keeps the bounds valid.  0: the reference's key only.  Ignored in the reference-order mode */
+	int32_t icp_point_seed;  /* 1 (default): every neighbour walk of the ICP pass / NN operator starts from a REAL candidate -- per DT voxel the engine keeps the
+	                          * leaf slot of a target point whose seed voxel is nearest (the exact EDT passes once more, carrying their arg-min; V^3 x 4
+	                          * bytes, built with the k-d tree) -- instead of from the distance-transform bound |q - c(v)| + DT[v] + 0.9 voxel, whose slack
+	                          * leaves far-from-surface queries a shell of dozens of candidate leaves.  Exactness does not depend on the table (any
+	                          * target point is a valid candidate; ties still go to the lowest index).  0: the DT bound */
 	float ub_share;          /* widened search: on top of the rot_batch parents drawn by smallest lower bound, this fraction more are drawn per batch by the
 	                          * smallest upper bound seen inside them (needs ub_tiebreak = 1; default 0 = none: measured slower) */
 } goicp_params;

@@ -326,6 +326,26 @@ def test_icp_fixed_point_sums_scale_and_repeat(pkg, bunny_model, bunny_data10):
     base.close()
 
 
+def test_icp_point_seed_is_exact(pkg, oracle_mod, bunny_model, bunny_data10):
+    """Params::icp_point_seed: the neighbour walks start from a real candidate read from the per-voxel nearest-target-point
+    table (the EDT passes carrying their arg-min) instead of from the distance-transform bound.  Any target point is a valid
+    candidate, so nothing may change: NN indices / distances bit-equal to brute force (queries near, far and outside the
+    grid), and ICP trajectories bit-identical with the table on and off."""
+    rng = np.random.default_rng(21)
+    q = np.concatenate([bunny_data10[:1500], rng.uniform(-1.5, 1.5, (1500, 3)).astype(np.float32), rng.uniform(-6.0, 6.0, (300, 3)).astype(np.float32)])
+    out = {}
+    for seed in (0, 1):
+        reg = pkg.Registration(bunny_model, bunny_data10, 1e-3, icp_point_seed=seed)
+        idx, d2 = reg.nn_query(q)
+        e, R, t = pkg.IterativeClosestPoint3D(reg, 30, 1e-7, np.eye(3), np.zeros(3)).run()
+        out[seed] = (idx, d2, e, R, t)
+        reg.close()
+    bi, bd = oracle_mod.nn_brute(bunny_model, q)
+    for seed in (0, 1):
+        assert np.array_equal(out[seed][0], bi) and np.array_equal(out[seed][1], bd)
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+
+
 def test_icp_step_decreases_error(pkg, bunny_model, bunny_data10):
     reg = pkg.Registration(bunny_model, bunny_data10, 1e-3)
     errs = [reg.icp_step().best_sse for _ in range(6)]

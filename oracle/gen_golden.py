@@ -11,6 +11,8 @@ Runs only in the build container (needs /root/reference).  It
      /root/reference, can replay them.
 
 usage: python oracle/gen_golden.py [--skip-full]     (full bunny e2e takes ~10 min of CPU)
+       python oracle/gen_golden.py --sub-configs     (only the strided skull / spanner fixtures of BASELINE configs[2], [3]:
+                                                      e2e_skull_sub.json, e2e_spanner_sub.json, inner_bnb_spanner.json; ~1 min)
 """
 import argparse
 import os
@@ -156,6 +158,7 @@ def main():
     rc = [p.wait() for p in procs]
     if any(rc):
         sys.exit("harness failed: %r" % rc)
+    sub_configs(h, "/tmp/goicp_gen_golden")
     print("fixtures written to", OUT)
 
 

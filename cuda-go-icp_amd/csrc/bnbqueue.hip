@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	QNode mine_nd{};
 	if (tid < n_sel) mine_nd = Q[sh.sel_pos[tid]];
 	bool to_tile = false;
-	if (n_sel >= qp.tile_min && qp.tile_spread > 0.f) {
+	if ((n_sel >= qp.tile_min || qp.tile_stats) && qp.tile_spread > 0.f) {
 		float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0.f;
 		if (tid < n_sel) { lo3[0] = hi3[0] = mine_nd.x; lo3[1] = hi3[1] = mine_nd.y; lo3[2] = hi3[2] = mine_nd.z; wmax = mine_nd.w; }
 		if (wave < 2) {
@@ -408,8 +408,12 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			spread = fmaxf(spread, fmaxf(sh.ext[0][3 + k], sh.ext[1][3 + k]) - fminf(sh.ext[0][k], sh.ext[1][k]));
 		spread += fmaxf(sh.ext_w[0], sh.ext_w[1]);                      // the children's centres reach w/4 .. 3w/4 beyond the corners
 		to_tile = spread <= qp.tile_spread;
+		if (qp.tile_stats && tid == 0) {
+			const float v = spread * qp.tile_stats_scale;                  // voxels
+			atomicAdd(&ctl->sel_hist[n_sel < 16 ? 0 : (n_sel < 32 ? 1 : (n_sel < 64 ? 2 : 3))][v <= 5.f ? 0 : (v <= 10.f ? 1 : (v <= 20.f ? 2 : 3))], n_sel);
+		}
 		if (to_tile && tid == 0) atomicAdd(&ctl->tile_hint, 1);
-		to_tile = to_tile && qp.tile_on != 0;
+		to_tile = to_tile && qp.tile_on != 0 && n_sel >= qp.tile_min;
 	}
 	if (tid == 0) {
 		if (to_tile) {
@@ -462,6 +466,7 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 		ctl->n_groups[0] = 0; ctl->n_groups[1] = 0; ctl->overflow = 0;
 		for (int k = 0; k < 8; k++) { ctl->work[0][k] = 0; ctl->work[1][k] = 0; }
 		ctl->n_tile_groups[0] = ctl->n_tile_groups[1] = 0; ctl->n_tile_segs[0] = ctl->n_tile_segs[1] = 0; ctl->tile_chunks = 1; ctl->tile_hint = 0; ctl->tile_total = 0;
+		for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) ctl->sel_hist[a][b] = 0;
 	}
 	if (s >= nsearch) return;
 	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241

@@ -114,6 +114,7 @@ struct QCtl {
 	int32_t tile_chunks;            // point chunks per segment of the last tile evaluation (its sums are chunk partials when > 1)
 	int32_t tile_hint;              // running count of (search, round) pairs that qualified for the tile list, whether it was on or not
 	int32_t tile_total;             // running count of expansions listed in the tile list
+	int32_t sel_hist[4][4];         // diagnostics (verbose): expansions selected, by [selection size < 16, < 32, < 64, >= 64][spread <= 5, <= 10, <= 20, > 20 voxels]
 };
 struct QTile {                      // buffers of the tile list (all null / zero: tiles off)
 	ParentRec* parents[2];
@@ -130,6 +131,8 @@ struct QParams {
 	int32_t tile_on;                // 1: searches that qualify are listed in the tile list this round (its evaluation is launched)
 	int32_t tile_min;               // fewest expansions for the tile list (a lane group of the tile kernel = one expansion)
 	float tile_spread;              // largest extent, per axis, of the selected nodes' translations (world units) for the tile list
+	int32_t tile_stats;             // 1: fill QCtl::sel_hist (verbose runs)
+	float tile_stats_scale;         // voxels per world unit
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
 struct QInit { int32_t slot; float best; float coeff; int32_t rot; };

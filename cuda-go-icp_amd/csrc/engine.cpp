@@ -1079,6 +1079,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		}
 	}
 	cnt_.tile_expansions += h_qctl_->tile_total;
+	if (p_.verbose) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) sel_hist_[a][b] += h_qctl_->sel_hist[a][b];
 	const double t2 = now_ms();
 	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
@@ -1467,6 +1468,7 @@ QParams Engine::queue_params() const
 	QParams qp{};
 	qp.tile_on = 0; qp.tile_min = std::max(8, p_.tile_min);
 	qp.tile_spread = tiles_usable() ? (float)((double)p_.tile_spread_vox / dt_.scale) : 0.f;
+	qp.tile_stats = p_.verbose ? 1 : 0; qp.tile_stats_scale = (float)dt_.scale;
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
@@ -1716,6 +1718,9 @@ void Engine::run()
 		std::fprintf(stderr, "[goicp] translation expansions by parent depth:");
 		for (int l = 0; l < 32; l++) if (level_hist_[l]) std::fprintf(stderr, " %d:%lld", l, level_hist_[l]);
 		std::fprintf(stderr, "\n");
+		std::fprintf(stderr, "[goicp] device-queue expansions by [selection size][spread of the selection in voxels <=5 <=10 <=20 >20], tile rounds %lld, from tiles %lld:\n", tile_rounds_, cnt_.tile_expansions);
+		const char* rows[4] = {"  n < 16 ", " 16..31  ", " 32..63  ", " 64..128 "};
+		for (int a = 0; a < 4; a++) std::fprintf(stderr, "[goicp]  %s %12lld %12lld %12lld %12lld\n", rows[a], sel_hist_[a][0], sel_hist_[a][1], sel_hist_[a][2], sel_hist_[a][3]);
 	}
 	register_end();
 }

@@ -252,6 +252,7 @@ private:
 	QTile qtile_{};                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
 	bool tiles_usable() const;
 	int tile_hint_seen_ = 0;              // QCtl::tile_hint at the last read-back
+	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration
 	long long tile_rounds_ = 0;           // rounds whose tile evaluation was launched
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging

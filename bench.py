@@ -15,7 +15,7 @@ N = 30 379 source; committed data fixtures, tests/golden/*.f32), distance transf
   value  = cube bounds evaluated by all ranks / wall time of the K timed steps (max over ranks).
 The headline batch is SIBLING-STRUCTURED (8 children per expansion, as the search produces them); SURVEY 8(d)'s literal
 microbench -- 65 536 unrelated cubes -- is `generic_path` / `roofline.frac_generic`, about half that rate.
-Also reported: `sustained` (the same step for >= 5 s: mean and slowest-window rate), `s2` (the HBM-bound configuration,
+Also reported: `sustained` (the same step for >= 8 s: mean and slowest-window rate), `s2` (the HBM-bound configuration,
 N = M = 1 M, DT 512^3: three launches and its HBM roofline from the committed PMC traffic), ICP iterations/s (NN + sums + SVD update, host round trip included), an end-to-end
 registration of the same clouds (exact cube-bound count / wall time), the roofline of the dominant
 kernel (HIP events on the launch stream) and the CPU baseline timed on the host cores: the reference's own
@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--prewarm", type=int, default=30, help="untimed setup steps before the W warm-up steps (GPU clock ramp); reported as setup_prewarm_steps")
     ap.add_argument("--expansions", type=int, default=8192, help="BnB expansions (x8 cubes) per step per GPU")
-    ap.add_argument("--sustain-s", type=float, default=5.0, help="length of the sustained leg, seconds (0 = skip)")
+    ap.add_argument("--sustain-s", type=float, default=8.0, help="length of the sustained leg, seconds (0 = skip); long enough for a 5-second SMI sampler to see the GPU busy")
     ap.add_argument("--s2-steps", type=int, default=3, help="launches of the S2 (1 M points, DT 512^3) leg in the default run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 
 	float best = S->best;
 	int count = S->count;
+	int stale = S->stale;
 	const int n_prev = S->n_parents;
 	// ------------------------------------------------------------------------------------------------------------
 	// digest: the bounds of the children evaluated in the previous round (8 per expansion, <= 256 children)
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			if (sh.red_ub[w2] < mub || (sh.red_ub[w2] == mub && sh.red_idx[w2] < midx)) { mub = sh.red_ub[w2]; midx = sh.red_idx[w2]; }
 		const bool improved = mub < best;
 		if (tid == 0 && mub < S->min_ub) S->min_ub = mub;
+		stale = improved ? 0 : stale + 1;
 		if (improved) best = mub;
 		if (improved && tid == midx) { S->bx = cx; S->by = cy; S->bz = cz; S->bw = cw; S->improved = 1; }
 		// push the children that can still improve on the incumbent (:327-335), unless the depth limit says leaf
@@ -215,7 +217,14 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	// ------------------------------------------------------------------------------------------------------------
 	// select: the K queued nodes with the smallest keys
 	// ------------------------------------------------------------------------------------------------------------
-	const int n = count, K = qp.K;
+	// round width: a search whose incumbent did not move in its last round is proving, not finding -- every queued node with
+	// best - lb >= SSEThresh has to be expanded whatever the order (the per-node stop rule below admits nothing else), so a wider
+	// round wastes no cube bound and saves rounds; a search that is still improving keeps qp.K (its later nodes may yet be pruned)
+	const int n = count;
+	int K = qp.K;
+	if (qp.stale_widen == 1) K = stale >= 3 ? min(4 * qp.K, kQueueMaxPop) : (stale >= 1 ? min(2 * qp.K, kQueueMaxPop) : qp.K);
+	else if (qp.stale_widen == 2) K = stale >= 1 ? min(4 * qp.K, kQueueMaxPop) : qp.K;
+	else if (qp.stale_widen == 3) K = stale >= 1 ? min(4 * qp.K, kQueueMaxPop) : min(2 * qp.K, kQueueMaxPop);
 	unsigned key[kQPer];
 	float lbv[kQPer];
 #pragma unroll
@@ -384,8 +393,8 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	// a 64-point patch of the cloud can reach under ALL of them fits the LDS tile) and that has enough of them to fill lanes ----
 	QNode mine_nd{};
 	if (tid < n_sel) mine_nd = Q[sh.sel_pos[tid]];
-	bool to_tile = false;
-	if ((n_sel >= qp.tile_min || qp.tile_stats) && qp.tile_spread > 0.f) {
+	bool to_tile = false, deep_now = false;
+	if (qp.tile_spread > 0.f) {
 		float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0.f;
 		if (tid < n_sel) { lo3[0] = hi3[0] = mine_nd.x; lo3[1] = hi3[1] = mine_nd.y; lo3[2] = hi3[2] = mine_nd.z; wmax = mine_nd.w; }
 		if (wave < 2) {
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			spread = fmaxf(spread, fmaxf(sh.ext[0][3 + k], sh.ext[1][3 + k]) - fminf(sh.ext[0][k], sh.ext[1][k]));
 		spread += fmaxf(sh.ext_w[0], sh.ext_w[1]);                      // the children's centres reach w/4 .. 3w/4 beyond the corners
 		to_tile = spread <= qp.tile_spread;
+		deep_now = to_tile;
 		if (qp.tile_stats && tid == 0) {
 			const float v = spread * qp.tile_stats_scale;                  // voxels
 			atomicAdd(&ctl->sel_hist[n_sel < 16 ? 0 : (n_sel < 32 ? 1 : (n_sel < 64 ? 2 : 3))][v <= 5.f ? 0 : (v <= 10.f ? 1 : (v <= 20.f ? 2 : 3))], n_sel);
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		__syncthreads();
 		if (filler) Q[sh.hole_pos[frank]] = moved;
 	}
-	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; S->tile = to_tile ? 1 : 0; }
+	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; S->tile = to_tile ? 1 : 0; S->deep = deep_now ? 1 : 0; S->stale = stale; }
 }
 
 __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, int nsearch, QParams qp, QCtl* __restrict__ ctl)
@@ -472,7 +482,7 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241
 	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY; S.deep = 0; S.stale = 0;
 }
 
 // the listed slots become fresh searches (continuous flow: slots are recycled while other searches keep running)
@@ -485,7 +495,7 @@ __global__ void bnb_init_list_kernel(QSearch* __restrict__ searches, QNode* __re
 	QSearch& S = searches[in.slot];
 	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot;
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY; S.deep = 0; S.stale = 0;
 }
 
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream)

@@ -99,6 +99,8 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 	float bx, by, bz, bw;           // best child (corner, width), valid when improved
 	int32_t tile;                   // this round's expansions are in the tile list (parent_off counts in that list)
 	float min_ub;                   // smallest upper bound of any child this search evaluated (whether or not it beat the incumbent)
+	int32_t deep;                   // diagnostics: the last selection lay within the tile spread
+	int32_t stale;                  // rounds since this search's incumbent last improved (QParams::stale_widen)
 };
 struct TileSeg { int32_t off, n, rot; };   // tile list: a search's expansions parents[off .. off+n), n <= 64, one rotation
 struct QCtl {
@@ -131,6 +133,7 @@ struct QParams {
 	int32_t tile_on;                // 1: searches that qualify are listed in the tile list this round (its evaluation is launched)
 	int32_t tile_min;               // fewest expansions for the tile list (a lane group of the tile kernel = one expansion)
 	float tile_spread;              // largest extent, per axis, of the selected nodes' translations (world units) for the tile list
+	int32_t stale_widen;            // 1: a search whose incumbent did not improve in its last round expands up to 2 K nodes, after three such rounds 4 K (<= 128)
 	int32_t tile_stats;             // 1: fill QCtl::sel_hist (verbose runs)
 	float tile_stats_scale;         // voxels per world unit
 };

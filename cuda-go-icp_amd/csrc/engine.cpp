@@ -1068,11 +1068,11 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		t_wait_ += now_ms() - t1;
 		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
 		if ((h_qctl_->n_groups[last] == 0 && h_qctl_->n_tile_groups[last] == 0) || cancel_.load()) break;
-		chunk = 4;
 		if (tiles && p_.lds_tiles == 2) { qp.tile_on = h_qctl_->tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = h_qctl_->tile_hint; }
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)
+		chunk = 4;
 		if (p_.adaptive_k && K >= 32) {
 			const int active_est = (h_qctl_->n_groups[last] + h_qctl_->n_tile_groups[last] + qp.K - 1) / qp.K;       // searches that filled their quota
 			qp.K = active_est <= 16 ? kQueueMaxPop : (active_est <= 64 ? std::min(kQueueMaxPop, 2 * K) : K);
@@ -1469,6 +1469,8 @@ QParams Engine::queue_params() const
 	qp.tile_on = 0; qp.tile_min = std::max(8, p_.tile_min);
 	qp.tile_spread = tiles_usable() ? (float)((double)p_.tile_spread_vox / dt_.scale) : 0.f;
 	qp.tile_stats = p_.verbose ? 1 : 0; qp.tile_stats_scale = (float)dt_.scale;
+	qp.stale_widen = p_.adaptive_k ? p_.stale_widen : 0;
+
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;

@@ -45,6 +45,9 @@ struct Params {
 	int lds_tiles = 2;            // LDS-staged DT tiles for inner searches whose selected nodes lie within a few voxels of each other (deep rounds): 0 off, 1 the
 	                              // tile evaluation is launched every round, 2 only while the previous rounds had searches that qualify (default)
 	float tile_spread_vox = 10.f; // ... "a few": largest extent of a search's selected translations, in DT voxels (measured: the tile kernel is 1.7x the gathering one at 3 voxels, 1.3x at 5, even at 10)
+	int stale_widen = 1;          // adaptive_k: an inner search whose incumbent did not improve in its last round(s) is PROVING, not finding: every queued node whose lower
+	                              // bound is more than SSEThresh below the incumbent has to be expanded whatever the order, so a wider round wastes nothing -- its width
+	                              // doubles after one such round and again after three (lower-bound searches almost never improve; upper-bound searches until they settle)
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)

@@ -145,6 +145,10 @@ typedef struct goicp_params {
 	                          * previous rounds had searches that qualify (shallow registrations never pay for it); 1: every round; 0: off */
 	float tile_spread_vox;   /* default 10 */
 	int32_t tile_min;        /* fewest expansions of a search for the tile list (default and minimum 8) */
+	int32_t stale_widen;     /* adaptive_k refinement (default 1).  An inner search whose incumbent did not improve in its last round is PROVING, not finding: every
+	                          * queued node whose lower bound is more than SSEThresh below the incumbent has to be expanded whatever the order (the per-node
+	                          * stop rule, jly_goicp.cpp:257, admits nothing else), so a wider round wastes no cube bound and saves rounds.  1: its round
+	                          * doubles after one such round and again after three; 2: x4 after one; 0: off */
 	int32_t ub_tiebreak;     /* opt-in (default 0: measured, no registration got faster -- ties are rare beyond level 2).  1 (widened search only): rotation cubes of EQUAL lower bound and width are
 	                          * expanded in the order of the smallest upper bound their own inner search saw (the basin most likely to refine the
 	                          * optimum first).  The reference leaves that order to its heap (src/goicp/jly_goicp.h:44-56); any order of a best-first

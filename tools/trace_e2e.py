@@ -33,7 +33,7 @@ else:
     model, data, _, _ = synth.make_pair(**{k: synth.S1[k] for k in ("seed", "M", "N")}); m0 = 1e-4
 reps = kw.pop("reps", 1)
 for r in range(reps):
-    eng = pkg.FastGoICP(model, data, mse or m0, verbose=2 if r == 0 else 0, **kw)
+    eng = pkg.FastGoICP(model, data, mse or m0, verbose=2 if r == reps - 1 else 0, **kw)
     t0 = time.perf_counter()
     eng.run()
     wall = time.perf_counter() - t0

@@ -2,7 +2,7 @@
 """LDS-staged DT tiles against direct gathers on batches shaped like the deep rounds of inner searches (GPU box).
 A segment = one search: one rotation, n = 64 translation nodes of depth d forming a 4x4x4 block of neighbours around a
 random translation.  Prints per depth: the two kernels' time per 65 536 cube bounds, the largest relative difference of
-their (ub, lb), and how many 64-point patches could be staged.  usage: python3 tools/tile_probe.py [bunny|s2]"""
+their (ub, lb), and how many 64-point patches could be staged.  usage: python3 tools/tile_probe.py [bunny|s2] [depth,depth,...]"""
 import ctypes as C
 import os
 import sys
@@ -18,6 +18,7 @@ pkg.load_library()
 from cuda_go_icp_amd import binding as B  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "bunny"
+DEPTHS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (4, 5, 6, 7, 8, 10)
 if which == "bunny":
     g = os.path.join(ROOT, "tests", "golden")
     tg = np.fromfile(os.path.join(g, "model_bunny.f32"), dtype="<f4").reshape(-1, 3)
@@ -33,7 +34,7 @@ fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
 rng = np.random.default_rng(7)
 nseg, n = 128, 64
 for chunks in ((16, 32) if which == "bunny" else (64,)):
-    for depth in (4, 5, 6, 7, 8, 10):
+    for depth in DEPTHS:
         w = np.float32(1.0 / (1 << depth))
         rots = np.stack([pkg.fgoicp.rodrigues(rng.uniform(-2.0, 2.0, 3)) for _ in range(nseg)]).astype(np.float32).reshape(-1)
         par = np.zeros((nseg, n, 4), np.float32)

@@ -38,5 +38,5 @@ for r in range(reps):
     eng.run()
     wall = time.perf_counter() - t0
     c = eng.counters
-    print("%s %s: %.2f ms sse %.6g cubes %d rot %d icp runs %d iters %d rounds %d" % (which, kw, wall * 1e3, eng.get_best_error(), c.cubes, c.rot_pops, c.icp_runs, c.icp_iters, c.bounds_launches), flush=True)
+    print("%s %s: %.2f ms sse %.6g cubes %d rot %d icp runs %d iters %d rounds %d" % (which, kw, wall * 1e3, eng.get_best_error(), c.cubes, c.rot_pops, c.icp_runs, c.icp_iters, c.bounds_launches) + " queue fallbacks %d" % c.queue_fallbacks, flush=True)
     eng.registration.close()

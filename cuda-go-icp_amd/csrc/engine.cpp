@@ -99,6 +99,7 @@ struct Engine::InnerSearch {
 	std::vector<Node> parents;    // popped this round
 	long long pops = 0, cubes = 0;
 	float min_ub = std::numeric_limits<float>::infinity();   // smallest upper bound of any cube evaluated
+	int stale = 0;                // rounds since the incumbent last improved (host fallback: round widening)
 };
 
 float Engine::rot_coeff(int level) const
@@ -1105,18 +1106,25 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 		bnb_ms_ += now_ms() - t_begin;
 		if (ok) return;
 		// a queue outgrew its slab: the batch is re-run through the host queues (the searches have not been touched)
+		run_inner_host(searches, rots, true);
+		return;
 	}
 	run_inner_host(searches, rots);
 }
 
 // Lock-step rounds of all the given inner searches: pop up to trans_batch nodes per search, evaluate the
 // 8 children of every popped node in ONE launch, digest the bounds, repeat until every search stops.
-void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots)
+// fallback (a device queue outgrew its slab -- a search with tens of thousands of queued nodes): the round of a search whose
+// incumbent did not improve in its last round grows x4, then x16 (the stale-incumbent rule of the device queues: a search that
+// is proving expands every node with best - lb >= SSEThresh whatever the order, and the host's heap has no 128-node limit), so
+// the re-run is a few hundred large launches instead of thousands of small ones
+void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots, bool fallback)
 {
 	DeviceGuard guard(dev_);
 	const double t_begin = now_ms();
 	struct Acc { double& a; double t0; ~Acc() { a += now_ms() - t0; } } acc{bnb_ms_, t_begin};
-	const int K = std::max(1, p_.trans_batch);
+	const int K0 = std::max(1, p_.trans_batch);
+	const bool widen = fallback && p_.adaptive_k && p_.stale_widen && K0 > 1;
 	const size_t nrot = rots.size();
 	ensure_batch(1, nrot);
 	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
@@ -1134,6 +1142,7 @@ void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vect
 		for (auto* s : grp[k]) {
 			s->parents.clear();
 			if (s->done) continue;
+			const int K = !widen ? K0 : (s->stale >= 3 ? 16 * K0 : (s->stale >= 1 ? 4 * K0 : K0));
 			while ((int)s->parents.size() < K && !s->pq.empty()) {
 				const Node n = s->pq.top();
 				if (s->best - n.lb < sse_thresh_) {           // jly_goicp.cpp:257
@@ -1169,7 +1178,8 @@ void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vect
 		Stage& st = stage_[k];
 		HIPCHK(hipEventSynchronize(st.ev));
 		size_t o = 0;
-		for (auto* s : grp[k])
+		for (auto* s : grp[k]) {
+			const float best_before = s->best;
 			for (const Node& par : s->parents) {
 				Node c{};
 				c.w = par.w / 2;
@@ -1186,6 +1196,8 @@ void Engine::run_inner_host(std::vector<InnerSearch*>& searches, const std::vect
 					s->pq.push(c);
 				}
 			}
+			if (!s->parents.empty()) s->stale = s->best < best_before ? 0 : s->stale + 1;
+		}
 	};
 	auto timed = [&](double& acc, auto&& fn) { const double t0 = now_ms(); auto r = fn(); acc += now_ms() - t0; return r; };
 	bool fly[2] = {timed(t_submit_, [&] { return submit(0); }), !grp[1].empty() && submit(1)};
@@ -1493,7 +1505,7 @@ void Engine::flow_fallback()
 		u.rot_slot = l.rot_slot = 0; u.coeff = 0.f; l.coeff = rot_coeff(f.kid.node.l); u.best = l.best = f.incumbent;
 		u.pq.push(trans_root_); l.pq.push(trans_root_);
 		std::vector<InnerSearch*> ptr{&u, &l};
-		run_inner_host(ptr, rots);
+		run_inner_host(ptr, rots, true);
 		if (handle_ub(f.kid, SearchOut{u.best, u.improved, u.best_node, u.pops, u.cubes, u.min_ub})) return;
 		handle_lb(f.kid, SearchOut{l.best, l.improved, l.best_node, l.pops, l.cubes, l.min_ub});
 	}

@@ -164,7 +164,7 @@ private:
 	void ensure_batch(size_t B, size_t K);
 	void ensure_stage(int k, size_t B);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
-	void run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
+	void run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots, bool fallback = false);
 	bool run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);   // false: a queue overflowed, nothing was changed
 	void ensure_queues(size_t nsearch);
 	void process_parents(const std::vector<Node>& parents);

@@ -485,6 +485,16 @@ def main():
             generic = {"workload": "SURVEY 8(d) microbench batch: %d independent cubes (centres U[-0.5,0.5]^3, half-width 1/64), 8 rotations in the pi-ball, every second a lb pass" % Bc,
                        "launch_ms": round(gms.value, 4), "cube_bounds_per_s": round(Bc / (gms.value * 1e-3), 1),
                        "Glookup_per_s": round(lookups / (gms.value * 1e-3) / 1e9, 2), "frac_of_peak": round(lookups / (gms.value * 1e-3) / 1e9 / peak, 4)}
+            # the same batch through goicp_eval_bounds_device_grouped: bucketed on the device by (rotation, pass, translation cell), evaluated,
+            # written back in the caller's order -- bit-identical bounds; the grouping kernels are inside the timed region
+            ref_ub = d_ub.clone()
+            ggms = C.c_float()
+            B.check(lib.goicp_time_bounds_device_grouped(h, gd_rots.data_ptr(), len(g_rots), gd_cubes.data_ptr(), len(g_recs), d_ub.data_ptr(), d_lb.data_ptr(), 5, C.byref(ggms)))
+            assert torch.equal(ref_ub, d_ub), "grouped evaluation changed a bound"
+            generic["grouped"] = {"call_ms": round(ggms.value, 4), "cube_bounds_per_s": round(Bc / (ggms.value * 1e-3), 1),
+                                  "frac_of_peak": round(lookups / (ggms.value * 1e-3) / 1e9 / peak, 4),
+                                  "is": "goicp_eval_bounds_device_grouped: device counting sort by (rotation, pass, 12-bit Morton cell of the translation) + evaluation + un-permute, all timed; same bits"}
+            roofline["frac_generic_grouped"] = generic["grouped"]["frac_of_peak"]
             # `frac` is on the sibling-structured batch the search produces; SURVEY 8(d)'s literal microbench batch gives:
             roofline["frac_generic"] = generic["frac_of_peak"]
             roofline["achieved_generic"] = generic["Glookup_per_s"]

@@ -117,6 +117,8 @@ SYMBOLS = {
     "goicp_eval_bounds": (C.c_int, [_vp, _fp, _fp, C.c_size_t, C.c_int32, _fp, _fp]),
     "goicp_eval_bounds_batch": (C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(CCube), C.c_size_t, _fp, _fp]),
     "goicp_eval_bounds_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "goicp_eval_bounds_device_grouped": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "goicp_time_bounds_device_grouped": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int32, _fp]),
     "goicp_reduce_min_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "goicp_time_bounds_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_int32, _fp]),
     "goicp_rot_coeff": (C.c_float, [_vp, C.c_int32]),

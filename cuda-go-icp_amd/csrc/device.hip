@@ -617,6 +617,97 @@ hipError_t launch_bounds_tile_queue(const float4* src, int N, const DtDesc& dt, 
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouping of an UNRELATED cube batch (the operator API's arbitrary batches; SURVEY 8(d)'s microbench): cubes are bucketed by
+// (rotation, pass, 12-bit Morton cell of the translation) with a counting sort, evaluated in that order -- a workgroup's eight
+// cubes then share their rotation and lie in one translation cell, and neighbouring workgroups gather from neighbouring DT
+// lines -- and the bounds are written back to the caller's order.  Bounds are per cube, so the order changes no bit of them
+// (tools/generic_probe.py: 3.75 -> 2.2 ms per 65 536 unrelated cubes on the bunny).  The search never needs this: its expansions
+// arrive grouped by search, eight siblings at a time.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGroupCellBits = 4;                  // per axis: 16 x 16 x 16 translation cells over [-0.5, 0.5]^3 (clamped outside)
+__device__ __forceinline__ unsigned cube_bucket(const CubeRec& c, int nrots)
+{
+	unsigned m = 0;
+	const float t[3] = {c.tx, c.ty, c.tz};
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const int q = min(max((int)((t[k] + 0.5f) * (float)(1 << kGroupCellBits)), 0), (1 << kGroupCellBits) - 1);
+#pragma unroll
+		for (int b = 0; b < kGroupCellBits; b++) m |= (unsigned)((q >> b) & 1) << (3 * b + k);
+	}
+	const unsigned rot = (unsigned)min(max(c.rot, 0), nrots - 1);
+	return ((rot * 2u + (c.coeff > 0.f ? 1u : 0u)) << (3 * kGroupCellBits)) | m;
+}
+__global__ void cube_hist_kernel(const CubeRec* __restrict__ cubes, int B, int nrots, unsigned* __restrict__ hist)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < B) atomicAdd(&hist[cube_bucket(cubes[i], nrots)], 1u);
+}
+// exclusive scan of nbins counters, one workgroup of 1024 threads (nbins <= 1024 * 64)
+__global__ __launch_bounds__(1024) void cube_scan_kernel(unsigned* __restrict__ hist, int nbins)
+{
+	__shared__ unsigned wtot[16];
+	const int per = (nbins + 1023) / 1024, b0 = threadIdx.x * per;
+	unsigned local = 0;
+	for (int k = 0; k < per; k++) if (b0 + k < nbins) local += hist[b0 + k];
+	unsigned incl = local;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
+	if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	unsigned before = 0;
+	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wtot[w];
+	unsigned run = before + incl - local;
+	for (int k = 0; k < per; k++) if (b0 + k < nbins) { const unsigned c = hist[b0 + k]; hist[b0 + k] = run; run += c; }
+}
+__global__ void cube_scatter_kernel(const CubeRec* __restrict__ cubes, int B, int nrots, unsigned* __restrict__ offs, CubeRec* __restrict__ sorted, int* __restrict__ perm)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= B) return;
+	const CubeRec c = cubes[i];
+	const unsigned pos = atomicAdd(&offs[cube_bucket(c, nrots)], 1u);        // order inside a bucket is arbitrary: the bounds do not depend on it
+	sorted[pos] = c;
+	perm[pos] = i;
+}
+__global__ void cube_unpermute_kernel(const float* __restrict__ ub_s, const float* __restrict__ lb_s, const int* __restrict__ perm, int B, float* __restrict__ ub,
+                                      float* __restrict__ lb)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= B) return;
+	const int o = perm[i];
+	ub[o] = ub_s[i]; lb[o] = lb_s[i];
+}
+size_t bounds_grouped_scratch_bytes(int B, int nrots)
+{
+	const size_t nbins = (size_t)nrots * 2 << (3 * kGroupCellBits);
+	return sizeof(unsigned) * nbins + (sizeof(CubeRec) + sizeof(int) + 2 * sizeof(float)) * (size_t)B + 256;
+}
+hipError_t launch_bounds_grouped(const float4* src, int N, const DtDesc& dt, const Rot9* rots, int nrots, const CubeRec* cubes, int B, void* group_scratch,
+                                 float* scratch, float* ub, float* lb, hipStream_t stream)
+{
+	if (B <= 0 || N <= 0) return hipSuccess;
+	const int nbins = (nrots * 2) << (3 * kGroupCellBits);
+	if (nrots < 1 || nbins > 1024 * 64) return hipErrorInvalidValue;
+	char* p = static_cast<char*>(group_scratch);
+	unsigned* hist = reinterpret_cast<unsigned*>(p); p += sizeof(unsigned) * (size_t)nbins;
+	p = reinterpret_cast<char*>(((uintptr_t)p + 63) & ~(uintptr_t)63);
+	CubeRec* sorted = reinterpret_cast<CubeRec*>(p); p += sizeof(CubeRec) * (size_t)B;
+	int* perm = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)B;
+	float* ub_s = reinterpret_cast<float*>(p); p += sizeof(float) * (size_t)B;
+	float* lb_s = reinterpret_cast<float*>(p);
+	hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)nbins, stream);
+	if (e != hipSuccess) return e;
+	const dim3 g((B + 255) / 256), b(256);
+	hipLaunchKernelGGL(cube_hist_kernel, g, b, 0, stream, cubes, B, nrots, hist);
+	hipLaunchKernelGGL(cube_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, nbins);
+	hipLaunchKernelGGL(cube_scatter_kernel, g, b, 0, stream, cubes, B, nrots, hist, sorted, perm);
+	e = launch_bounds(src, N, dt, rots, sorted, nullptr, B, scratch, ub_s, lb_s, stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(cube_unpermute_kernel, g, b, 0, stream, ub_s, lb_s, perm, B, ub, lb);
+	return hipGetLastError();
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,

@@ -80,6 +80,11 @@ size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out);
 hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream);
 
+// an UNRELATED cube batch, evaluated grouped by (rotation, pass, translation cell) and written back in the caller's order (same bits)
+size_t bounds_grouped_scratch_bytes(int B, int nrots);
+hipError_t launch_bounds_grouped(const float4* src, int N, const DtDesc& dt, const Rot9* rots, int nrots, const CubeRec* cubes, int B, void* group_scratch,
+                                 float* scratch, float* ub, float* lb, hipStream_t stream);
+
 // trimmed form: only the `inliers` smallest residuals of each cube are summed (jly_goicp.cpp:293-315)
 hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents, int B,
                               int inliers, float* ub, float* lb, hipStream_t stream);

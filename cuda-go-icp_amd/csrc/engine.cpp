@@ -611,13 +611,33 @@ void Engine::reduce_min_dev(const float* d_v, int n, float* d_min, int* d_idx, h
 	HIPCHK(launch_reduce_min(d_v, n, d_min, d_idx, s ? s : stream_));
 }
 
-float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters)
+void Engine::eval_bounds_dev_grouped(const Rot9* d_rots, int nrots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s)
 {
 	DeviceGuard guard(dev_);
-	eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_);   // sizes the scratch
+	if (inliers_ < (int)N_) { eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, s); return; }     // the trimmed kernel owns whole cubes: nothing to group
+	if (nrots < 1 || nrots > 16) throw std::invalid_argument("goicp: grouped bounds take 1..16 rotations");
+	const size_t need = bounds_scratch_floats(B, (int)N_, nullptr, nullptr);
+	if (need > cap_scratch_) {
+		HIPCHK(hipStreamSynchronize(stream_));
+		if (s && s != stream_) HIPCHK(hipStreamSynchronize(s));
+		hipFree(d_scratch_);
+		d_scratch_ = nullptr; cap_scratch_ = 0;
+		HIPCHK(hipMalloc(&d_scratch_, sizeof(float) * need));
+		cap_scratch_ = need;
+	}
+	void* gs = scratch_bytes(bounds_grouped_scratch_bytes(B, nrots));
+	HIPCHK(launch_bounds_grouped(d_src_, (int)N_, bounds_dt(), d_rots, nrots, d_cubes, B, gs, d_scratch_, d_ub, d_lb, s ? s : stream_));
+	cnt_.bounds_launches++;
+}
+
+float Engine::time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters, int grouped_nrots)
+{
+	DeviceGuard guard(dev_);
+	auto once = [&] { if (grouped_nrots > 0) eval_bounds_dev_grouped(d_rots, grouped_nrots, d_cubes, B, d_ub, d_lb, stream_); else eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_); };
+	once();   // sizes the scratch
 	HIPCHK(hipStreamSynchronize(stream_));
 	HIPCHK(hipEventRecord(ev0_, stream_));
-	for (int i = 0; i < iters; i++) eval_bounds_dev(d_rots, d_cubes, B, d_ub, d_lb, stream_);
+	for (int i = 0; i < iters; i++) once();
 	HIPCHK(hipEventRecord(ev1_, stream_));
 	HIPCHK(hipEventSynchronize(ev1_));
 	float ms = 0.f;

@@ -110,7 +110,8 @@ public:
 	void eval_bounds_batch(const float* rots9, size_t K, const CubeRec* cubes, size_t B, float* ub, float* lb);
 	void eval_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s, const ParentRec* d_parents = nullptr);
 	void reduce_min_dev(const float* d_v, int n, float* d_min, int* d_idx, hipStream_t s);
-	float time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters);
+	float time_bounds_dev(const Rot9* d_rots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, int iters, int grouped_nrots = 0);
+	void eval_bounds_dev_grouped(const Rot9* d_rots, int nrots, const CubeRec* d_cubes, int B, float* d_ub, float* d_lb, hipStream_t s);
 	float eval_sse(const float R[9], const float t[3]);
 	float inner_bnb(const float R[9], int level, float incumbent, float best_node[4], Counters* c);
 	float icp_run(float R[9], float t[3], int max_iter, float err_diff, int* iters);

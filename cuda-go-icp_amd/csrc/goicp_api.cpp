@@ -254,6 +254,24 @@ int goicp_eval_bounds_device(goicp_handle h, const void* d_rots, const void* d_c
 	});
 }
 
+int goicp_eval_bounds_device_grouped(goicp_handle h, const void* d_rots, size_t n_rots, const void* d_cubes, size_t B, void* d_ub, void* d_lb, void* stream)
+{
+	REQUIRE(h && d_rots && d_cubes && d_ub && d_lb && B > 0 && n_rots >= 1 && n_rots <= 16);
+	return guarded([&] {
+		h->e->eval_bounds_dev_grouped(static_cast<const goicp::Rot9*>(d_rots), (int)n_rots, static_cast<const goicp::CubeRec*>(d_cubes), (int)B,
+		                              static_cast<float*>(d_ub), static_cast<float*>(d_lb), static_cast<hipStream_t>(stream));
+	});
+}
+
+int goicp_time_bounds_device_grouped(goicp_handle h, const void* d_rots, size_t n_rots, const void* d_cubes, size_t B, void* d_ub, void* d_lb, int32_t iters, float* ms)
+{
+	REQUIRE(h && d_rots && d_cubes && d_ub && d_lb && B > 0 && iters > 0 && ms && n_rots >= 1 && n_rots <= 16);
+	return guarded([&] {
+		*ms = h->e->time_bounds_dev(static_cast<const goicp::Rot9*>(d_rots), static_cast<const goicp::CubeRec*>(d_cubes), (int)B, static_cast<float*>(d_ub),
+		                            static_cast<float*>(d_lb), iters, (int)n_rots);
+	});
+}
+
 int goicp_reduce_min_device(goicp_handle h, const void* d_values, size_t n, void* d_min, void* d_argmin, void* stream)
 {
 	REQUIRE(h && d_values && d_min && n > 0 && n <= 0x7fffffffu && ((uintptr_t)d_values & 15) == 0);

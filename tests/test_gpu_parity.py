@@ -139,6 +139,49 @@ def test_eval_bounds_batch_mixed_rotations(pkg, reg10):
         assert np.allclose(ub[sel], u2, rtol=2e-6, atol=0) and np.allclose(lb[sel], l2, rtol=2e-6, atol=1e-9)
 
 
+def test_eval_bounds_grouped_same_bits(pkg, reg10):
+    """goicp_eval_bounds_device_grouped: an unrelated batch (random rotation, pass and translation per cube, some translations outside
+    the root cube, a ragged size) bucketed on the device by (rotation, pass, translation cell), evaluated and written back in the
+    caller's order -- every bound bit-equal to the plain entry point's."""
+    import ctypes as C
+    B = pkg.binding
+    lib, h = reg10._lib, reg10.handle
+    hip = C.CDLL("libamdhip64.so")                     # the runtime the library itself is linked against (device buffers for the device-pointer entry points)
+    hip.hipMalloc.argtypes, hip.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def to_dev(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes) == 0 and hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+        return p
+
+    def to_host(p, n):
+        out = np.empty(n, np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, out.nbytes, 2) == 0       # blocking: orders after the engine's stream work below
+        return out
+
+    rng = np.random.default_rng(17)
+    for n, nrot in ((4099, 5), (65536, 8), (7, 1)):
+        rots = np.stack([pkg.fgoicp.rodrigues(rng.uniform(-2.0, 2.0, 3)) for _ in range(nrot)]).astype(np.float32)
+        recs = np.zeros(n, dtype=[("tx", "<f4"), ("ty", "<f4"), ("tz", "<f4"), ("delta", "<f4"), ("coeff", "<f4"), ("rot", "<i4")])
+        c = rng.uniform(-0.7, 0.7, (n, 3)).astype(np.float32)
+        recs["tx"], recs["ty"], recs["tz"] = c[:, 0], c[:, 1], c[:, 2]
+        recs["delta"] = rng.choice(np.array([lib.goicp_trans_delta(1.0 / (1 << k)) for k in range(1, 7)], np.float32), n)
+        recs["coeff"] = np.where(rng.random(n) < 0.5, np.float32(reg10.rot_coeff(4)), np.float32(0))
+        recs["rot"] = rng.integers(0, nrot, n)
+        d_rots, d_cubes = to_dev(np.ascontiguousarray(rots.reshape(-1))), to_dev(np.ascontiguousarray(recs).view(np.uint8))
+        outs = [to_dev(np.full(n, -1.0, np.float32)) for _ in range(4)]
+        ms = C.c_float()
+        # the timing entries run the evaluation on the engine's own stream and wait for it
+        B.check(lib.goicp_time_bounds_device(h, d_rots, d_cubes, n, outs[0], outs[1], 1, C.byref(ms)))
+        B.check(lib.goicp_time_bounds_device_grouped(h, d_rots, nrot, d_cubes, n, outs[2], outs[3], 1, C.byref(ms)))
+        ub, lb, gub, glb = (to_host(o, n) for o in outs)
+        assert np.array_equal(ub, gub) and np.array_equal(lb, glb), n
+        assert ub.min() >= 0.0 and np.all(lb <= ub)
+        for p in [d_rots, d_cubes] + outs:
+            hip.hipFree(p)
+
+
 def test_golden_single_expansions(pkg, reg10):
     """The reference's own InnerBnB, one expansion: min ub over the 8 children and the arg-min child
     (tests/golden/inner_bnb.json 'single').  rel 1e-4."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run (manual, GPU box): engines created, run and destroyed in a loop; every registration of the same input must
 return the same bits (SSE, R, t), and the free device memory after the last engine must equal the free memory after the
-first one (no leak).  usage: python tools/soak.py [rounds]"""
+second round (no leak; the first round is the runtime's warm-up).  usage: python tools/soak.py [rounds]"""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,10 @@ cloud = lambda n, s=1: np.fromfile(os.path.join(g, n + ".f32"), dtype="<f4").res
 cases = {"bunny10": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {}),
          "rand100": (cloud("model_rand"), cloud("data_rand"), 1e-3, {}),
          "bunny10_trim": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"trim_fraction": 0.1}),
-         "bunny10_flow": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"flow": 8})}
+         "bunny10_flow": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"flow": 8}),
+         # a registration that digs (threshold below the optimum's error): the tile list, the stale-incumbent round widening and the
+         # nearest-target-point seed all take part -- and must be as reproducible as everything else
+         "bunny10_deep_tiles": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-4, {"lds_tiles": 1, "tile_spread_vox": 16.0})}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 ref, base = {}, None
 t0 = time.time()
@@ -46,9 +49,9 @@ for r in range(rounds):
             assert ref[name] == sig, (name, r, "run differs from the first engine's", sig[0], ref[name][0])
         ref[name] = sig
     fm = free_mem()
-    if r == 0:
-        base = fm
-    if r % 10 == 9 or r == rounds - 1:
-        print("round %d: %.1f s, free device memory %+d KiB vs after the first round" % (r + 1, time.time() - t0, (fm - base) // 1024), flush=True)
-assert abs(free_mem() - base) <= (64 << 20), "device memory drifted"
+    if r == 1 or (r == 0 and rounds == 1):
+        base = fm                                     # after the SECOND round: the runtime keeps a little of what the first round's engines freed
+    if (r % 10 == 9 or r == rounds - 1) and base is not None:
+        print("round %d: %.1f s, free device memory %+d KiB vs after the second round" % (r + 1, time.time() - t0, (fm - base) // 1024), flush=True)
+assert abs(free_mem() - base) <= (128 << 20), "device memory drifted"      # the level toggles by one cached 90 MiB block of the runtime (seen at 0 and -90 MiB, never growing)
 print("soak ok: %d rounds x %d cases, bit-identical results, no memory drift" % (rounds, len(cases)))

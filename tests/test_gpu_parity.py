@@ -786,6 +786,20 @@ def test_cli_end_to_end(pkg, tmp_path):
     assert pkg.load_cloud(tmp_path / "viz.ply").shape == (200, 3)
     bad = subprocess.run([exe, str(tmp_path / "missing.toml")], capture_output=True, text=True)
     assert bad.returncode == 1 and "error" in bad.stderr.lower()
+    # a config that carries the [params.translation] table of the reference's files (+-1.0: a root of width 2, which the reference
+    # itself never applies): with --reference-root the CLI searches the CPU path's roots and reproduces the range-less run node for
+    # node; without the flag the range is applied (a larger root: more translation nodes).  --trim-fraction: the console's MSE is
+    # over the inliers, like output.toml's
+    (tmp_path / "cfg_ranges.toml").write_text((tmp_path / "cfg.toml").read_text() +
+                                              "[params.translation]\nxmin = -1.0\nxmax = 1.0\nymin = -1.0\nymax = 1.0\nzmin = -1.0\nzmax = 1.0\nsearch_depth = 12\n")
+    nodes = lambda o: int([l for l in o.splitlines() if l.startswith("Total Translation Nodes Searched")][0].split(":")[1])
+    ref_root = subprocess.run([exe, str(tmp_path / "cfg_ranges.toml"), "--reference-root"], check=True, capture_output=True, text=True, timeout=120).stdout
+    applied = subprocess.run([exe, str(tmp_path / "cfg_ranges.toml")], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert nodes(ref_root) == nodes(out) and nodes(applied) != nodes(out)
+    trimmed = subprocess.run([exe, str(tmp_path / "cfg.toml"), "--trim-fraction", "0.1"], check=True, capture_output=True, text=True, timeout=120).stdout
+    line = [l for l in trimmed.splitlines() if l.startswith("Searching over!")][0]
+    best, mse = float(line.split("Best Error:")[1].split()[0]), float(line.split("MSE")[1].strip(" )"))
+    assert abs(mse - best / int(100 * np.float32(0.9))) <= 1e-6 * max(mse, 1e-9)
 
 
 def test_cli_with_roctx_ranges(pkg, tmp_path):

@@ -1284,6 +1284,7 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
     B.check(lib.goicp_rccl_unique_id(ident))
     comm = B.CCommOps()
     B.check(lib.goicp_rccl_comm_create(ident, 0, 1, 0, C.byref(comm)))
+    B.check(lib.goicp_comm_set_timeout_ms(C.byref(comm), 5000))         # every collective below polls its stream against this deadline
     words = (C.c_uint64 * 3)(5, 1 << 40, 7)
     assert comm.allreduce_min_u64(comm.ctx, words, 3) == 0 and list(words) == [5, 1 << 40, 7]
     buf = (C.c_float * 12)(*range(12))
@@ -1291,6 +1292,7 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
     eng = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"])
     st = sharded.run_sharded_library(eng, comm, rot_pops_per_step=8)
     assert st["exchanges"] >= 1 and st["broadcasts"] >= 1 and eng.finished
+    assert st["status"] == 0 and st["failed_rank"] == -1 and st["wait_ms"] >= 0 and st["step_ms"] > 0
     assert eng.get_best_error() <= 1.02 * g["sse"] and eng.get_best_error() < g["sse_threshold"]
     assert rot_angle(eng.optR, np.array(g["R"])) <= 3e-2
     B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))

@@ -136,6 +136,7 @@ __device__ __forceinline__ float dt_distance(const DtDesc& dt, float qx, float q
 // Per-axis part of a voxel's element offset.  Both layouts are separable: offset = fx(x)+fy(y)+fz(z);
 // an out-of-grid index contributes kOutside (>= 2^30 > any in-grid sum, and three of them do not wrap),
 // so one unsigned compare of the sum tells whether the fast fetch is valid.
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kOutside = 0x40000000u;
 template <int LAYOUT, int AXIS>
 __device__ __forceinline__ unsigned axis_offset(const DtDesc& dt, int i)
@@ -244,7 +245,7 @@ __device__ __forceinline__ bool is_sibling_set(const CubeRec cr[kGroup])
 // contiguous chunk of the (k-d-ordered) source cloud; each point is loaded once (16 B) and
 // reused for the 8 cubes.
 // work item `work` of `total` = groups*chunks: one (cube group, point chunk) pair
-template <int LAYOUT>
+template <int LAYOUT, bool LEAN>
 __device__ __forceinline__ void bounds_work(
     int work, int total, const float4* __restrict__ src, int N, const DtDesc& dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
@@ -290,6 +291,76 @@ __device__ __forceinline__ void bounds_work(
 		// same float expression as in the generic path below, so the results are bit-identical
 		const SiblingSet ts{cr[0].tx, cr[1].tx, cr[0].ty, cr[2].ty, cr[0].tz, cr[4].tz};
 		const float delta = cr[0].delta, coeff = cr[0].coeff;
+		// LEAN (round 3; fp32 grids that fit the Infinity Cache): one exactness test per point on the smallest margin of the six
+		// indices; a wavefront whose indices are all inside the grid fetches without per-child checks; the eight children are
+		// accumulated as four x-sibling pairs in packed fp32 -- the same operations per element, bit-identical bounds.  Bunny
+		// microbench 1.837 -> 1.791 ms per launch, full registration 42.1 -> 40.6 ms; at 1 M points / 512^3 (HBM-bound) the same
+		// code is 13 % SLOWER (53.3 -> 60.5 ms), so the launch picks it by the size of the grid.
+		f2 ub2[4], lb2[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) { ub2[k] = f2{0.f, 0.f}; lb2[k] = f2{0.f, 0.f}; }
+		const f2 delta2 = f2{delta, delta};
+		if constexpr (LEAN && LAYOUT != 2)
+		for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
+			const float4 p = src[i];
+			const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
+			const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
+			const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+			const float qx[2] = {rx + ts.tx0, rx + ts.tx1}, qy[2] = {ry + ts.ty0, ry + ts.ty1}, qz[2] = {rz + ts.tz0, rz + ts.tz1};
+			float F[6] = {__fmaf_rn(qx[0] - dt.xmin_f, dt.scale_f, 0.5f), __fmaf_rn(qx[1] - dt.xmin_f, dt.scale_f, 0.5f),
+			              __fmaf_rn(qy[0] - dt.ymin_f, dt.scale_f, 0.5f), __fmaf_rn(qy[1] - dt.ymin_f, dt.scale_f, 0.5f),
+			              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
+			float worst = INFINITY;
+#pragma unroll
+			for (int k = 0; k < 6; k++) worst = fminf(worst, fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1));
+			int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
+			if (worst <= 0.f) {
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+				}
+			}
+			const unsigned V = (unsigned)dt.V;
+			const bool inside = (unsigned)ix[0] < V && (unsigned)ix[1] < V && (unsigned)iy[0] < V && (unsigned)iy[1] < V && (unsigned)iz[0] < V && (unsigned)iz[1] < V;
+			const float rho = coeff * p.w;
+			if (__all(inside)) {
+				unsigned fx[2], fy[2], fz[2];
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					if (LAYOUT == 0) { fx[k] = (unsigned)ix[k]; fy[k] = __umul24((unsigned)iy[k], V); fz[k] = __umul24((unsigned)iz[k], V * V); }
+					else {
+						fx[k] = (((unsigned)ix[k] >> 2) << 6) | ((unsigned)ix[k] & 3u);
+						fy[k] = (__umul24((unsigned)iy[k] >> 2, (unsigned)dt.VB) << 6) | (((unsigned)iy[k] & 3u) << 2);
+						fz[k] = (__umul24((unsigned)iz[k] >> 2, (unsigned)(dt.VB * dt.VB)) << 6) | (((unsigned)iz[k] & 3u) << 4);
+					}
+				}
+				const f2 rho2 = f2{rho, rho};
+				const char* gb = reinterpret_cast<const char*>(dt.grid);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const unsigned yz = fy[k & 1] + fz[k >> 1];
+					f2 v = f2{*reinterpret_cast<const float*>(gb + (size_t)((fx[0] + yz) << 2)), *reinterpret_cast<const float*>(gb + (size_t)((fx[1] + yz) << 2))};
+					v = v - rho2;
+					const f2 mm = __builtin_elementwise_max(v, f2{0.f, 0.f});
+					ub2[k] = ub2[k] + mm * mm;
+					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
+					lb2[k] = lb2[k] + dis * dis;
+				}
+			} else {
+				float m[kGroup];
+				sibling_residuals<LAYOUT>(dt, R0, ts, p, rho, m);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const f2 mm = f2{m[2 * k], m[2 * k + 1]};
+					ub2[k] = ub2[k] + mm * mm;
+					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
+					lb2[k] = lb2[k] + dis * dis;
+				}
+			}
+		}
+		else
 		for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
 			const float4 p = src[i];
 			float m[kGroup];
@@ -300,6 +371,10 @@ __device__ __forceinline__ void bounds_work(
 				const float dis = fmaxf(m[c] - delta, 0.f);
 				lb[c] += dis * dis;
 			}
+		}
+		if constexpr (LEAN && LAYOUT != 2) {
+#pragma unroll
+			for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[k].x; ub[2 * k + 1] = ub2[k].y; lb[2 * k] = lb2[k].x; lb[2 * k + 1] = lb2[k].y; }
 		}
 	} else
 	for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
@@ -366,7 +441,6 @@ __device__ __forceinline__ void bounds_work(
 #endif
 constexpr int kTileFloats = GOICP_TILE_FLOATS;    // 32 KB: up to 128 bricks of 4x4x4 voxels
 constexpr int kTilePatch = 64;                    // points per staged box
-typedef float f2 __attribute__((ext_vector_type(2)));
 // split of the cloud for `nseg` tile segments on a grid of `grid` workgroups: as many chunks (multiples of the 64-point
 // sub-patch) as it takes to give every workgroup an item, at most one sub-patch per chunk
 __host__ __device__ inline void tile_shape(int nseg, int N, int grid, int* chunks, int* chunk_pts)
@@ -603,6 +677,8 @@ hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const 
 	return hipGetLastError();
 }
 
+// the lean sibling path pays while the grid is cache-resident (<= the 256 MB Infinity Cache), not when the launch is HBM-bound
+static inline bool bounds_lean(const DtDesc& dt) { return (size_t)dt.V * dt.V * dt.V * sizeof(float) <= ((size_t)256 << 20); }
 constexpr int kTileQueueGrid = 256 * (160 * 1024 / (kTileFloats * 4 + 2048));   // as many workgroups per CU as their LDS allows (32 KB tiles: four)
 size_t bounds_tile_queue_scratch_floats(int max_groups)
 {
@@ -708,14 +784,14 @@ hipError_t launch_bounds_grouped(const float4* src, int N, const DtDesc& dt, con
 	return hipGetLastError();
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
     float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
-	bounds_work<LAYOUT>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red);
+	bounds_work<LAYOUT, LEAN>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red);
 }
 
 // The same evaluation for a batch whose size only the DEVICE knows (the device-resident BnB queues, bnbqueue.hip):
@@ -728,7 +804,7 @@ __host__ __device__ inline void bounds_shape(int B, int N, int* groups, int* chu
 // So the fixed grid draws its items dynamically: eight counters, one per XCD slot (blocks b and b+8 share an XCD), each
 // handing out the items whose index is congruent to that slot -- the XCD-aware tiling of bounds_work is kept, and the
 // fetch of the next item overlaps the evaluation of the current one.
-template <int LAYOUT>
+template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots, const ParentRec* __restrict__ parents,
     const int* __restrict__ d_groups, int* __restrict__ work8, int* __restrict__ d_chunks, float* __restrict__ scratch, float* __restrict__ ub_out,
@@ -750,7 +826,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	int item = next_item[0], buf = 0;
 	while (item * stride + slot < total) {
 		if (threadIdx.x == 0) next_item[buf ^ 1] = atomicAdd(ctr, 1);   // in flight while this item is evaluated
-		bounds_work<LAYOUT>(item * stride + slot, total, src, N, dt, rots, nullptr, parents, ngroups * kGroup, groups, chunks, chunk_pts, scratch, ub_out,
+		bounds_work<LAYOUT, LEAN>(item * stride + slot, total, src, N, dt, rots, nullptr, parents, ngroups * kGroup, groups, chunks, chunk_pts, scratch, ub_out,
 		                    lb_out, red);
 		__syncthreads();                                                 // `red` is reused by the next item; next_item is published
 		buf ^= 1;
@@ -969,6 +1045,7 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 	}
 	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
 	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
+	else if (dt.layout == 1 && bounds_lean(dt)) hipLaunchKernelGGL((bounds_queue_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
 	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
 	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
 	return hipGetLastError();
@@ -983,6 +1060,8 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
 	dim3 grid(groups * chunks), block(kBoundsThreads);
 	if (dt.layout == 0)
 		hipLaunchKernelGGL(bounds_kernel<0>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
+	else if (dt.layout == 1 && bounds_lean(dt))
+		hipLaunchKernelGGL((bounds_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
 	else if (dt.layout == 1)
 		hipLaunchKernelGGL(bounds_kernel<1>, grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb);
 	else

@@ -329,11 +329,12 @@ __device__ __forceinline__ void bounds_work(
 				unsigned fx[2], fy[2], fz[2];
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
-					if (LAYOUT == 0) { fx[k] = (unsigned)ix[k]; fy[k] = __umul24((unsigned)iy[k], V); fz[k] = __umul24((unsigned)iz[k], V * V); }
+					// BYTE offsets (the lean variant only runs on grids of at most 256 MB: they fit 32 bits)
+					if (LAYOUT == 0) { fx[k] = (unsigned)ix[k] << 2; fy[k] = __umul24((unsigned)iy[k], V) << 2; fz[k] = __umul24((unsigned)iz[k], V * V) << 2; }
 					else {
-						fx[k] = (((unsigned)ix[k] >> 2) << 6) | ((unsigned)ix[k] & 3u);
-						fy[k] = (__umul24((unsigned)iy[k] >> 2, (unsigned)dt.VB) << 6) | (((unsigned)iy[k] & 3u) << 2);
-						fz[k] = (__umul24((unsigned)iz[k] >> 2, (unsigned)(dt.VB * dt.VB)) << 6) | (((unsigned)iz[k] & 3u) << 4);
+						fx[k] = (((unsigned)ix[k] >> 2) << 8) | (((unsigned)ix[k] & 3u) << 2);
+						fy[k] = (__umul24((unsigned)iy[k] >> 2, (unsigned)dt.VB) << 8) | (((unsigned)iy[k] & 3u) << 4);
+						fz[k] = (__umul24((unsigned)iz[k] >> 2, (unsigned)(dt.VB * dt.VB)) << 8) | (((unsigned)iz[k] & 3u) << 6);
 					}
 				}
 				const f2 rho2 = f2{rho, rho};
@@ -341,7 +342,7 @@ __device__ __forceinline__ void bounds_work(
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const unsigned yz = fy[k & 1] + fz[k >> 1];
-					f2 v = f2{*reinterpret_cast<const float*>(gb + (size_t)((fx[0] + yz) << 2)), *reinterpret_cast<const float*>(gb + (size_t)((fx[1] + yz) << 2))};
+					f2 v = f2{*reinterpret_cast<const float*>(gb + (fx[0] + yz)), *reinterpret_cast<const float*>(gb + (fx[1] + yz))};
 					v = v - rho2;
 					const f2 mm = __builtin_elementwise_max(v, f2{0.f, 0.f});
 					ub2[k] = ub2[k] + mm * mm;

@@ -71,7 +71,7 @@ __device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, floa
 __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
                                                               const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
                                                               const float* __restrict__ ubs, const float* __restrict__ lbs,
-                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile)
+                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile, int* __restrict__ parent_search)
 {
 	__shared__ QShared sh;
 	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	const float coeff = S->coeff;
 	const int rot = S->rot;
 	if (tid < n_sel) (to_tile ? tile.parents[parity] : parents)[off + tid] = ParentRec{mine_nd.x, mine_nd.y, mine_nd.z, mine_nd.w, coeff, rot};
+	if (parent_search && !to_tile && tid < n_sel) parent_search[off + tid] = s;
 	__syncthreads();
 	// remove the selected nodes: the holes among the first m = n - n_sel positions are filled, in order, with the
 	// unselected nodes of the tail [m, n)  (at most n_sel <= 128 of each: the first two wavefronts do it)
@@ -482,7 +483,7 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 	q[(size_t)s * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};   // jly_goicp.cpp:50-53, :241
 	QSearch& S = searches[s];                                              // best / coeff / rot were uploaded by the host
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
-	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY; S.deep = 0; S.stale = 0;
+	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY; S.deep = 0; S.stale = 0;   // twin: uploaded by the host
 }
 
 // the listed slots become fresh searches (continuous flow: slots are recycled while other searches keep running)
@@ -493,7 +494,7 @@ __global__ void bnb_init_list_kernel(QSearch* __restrict__ searches, QNode* __re
 	const QInit in = list[i];
 	q[(size_t)in.slot * kQueueCap] = QNode{qp.root_x, qp.root_y, qp.root_z, qp.root_w, 0.f, 0.f};
 	QSearch& S = searches[in.slot];
-	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot;
+	S.best = in.best; S.coeff = in.coeff; S.rot = in.rot; S.twin = in.twin;
 	S.count = 1; S.done = 0; S.improved = 0; S.n_parents = 0; S.parent_off = 0; S.pops = 0; S.cubes = 0;
 	S.bx = S.by = S.bz = S.bw = 0.f; S.tile = 0; S.min_ub = INFINITY; S.deep = 0; S.stale = 0;
 }
@@ -513,7 +514,7 @@ hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QPara
 }
 
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile)
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile, int* parent_search)
 {
 	if (nsearch <= 0) return hipSuccess;
 	if (qp.K < 1 || qp.K > kQueueMaxPop) return hipErrorInvalidValue;
@@ -521,7 +522,7 @@ hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QPar
 	QParams q2 = qp;
 	if (tile && tile->ub) t = *tile;
 	else { q2.tile_on = 0; }                                               // no buffers: nothing may be listed there
-	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t);
+	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t, parent_search);
 	return hipGetLastError();
 }
 

@@ -244,19 +244,136 @@ __device__ __forceinline__ bool is_sibling_set(const CubeRec cr[kGroup])
 // of one BnB expansion: same rotation, neighbouring translations -> neighbouring DT voxels) and a
 // contiguous chunk of the (k-d-ordered) source cloud; each point is loaded once (16 B) and
 // reused for the 8 cubes.
+//
+// The lean sibling path over the points [p0, p1) of a chunk (round 3; fp32 grids that fit the Infinity Cache): one exactness test per
+// point on the smallest margin of the six indices; a wavefront whose indices are all inside the grid fetches without per-child checks;
+// the eight children are accumulated as four x-sibling pairs in packed fp32 -- the same operations per element as the checked path,
+// bit-identical bounds.  NP = 2: the SAME expansion listed by both searches of a rotation child (coeff[0] = the lower-bound pass's
+// coefficient, coeff[1] = 0 of the upper-bound pass): one gather serves both, only the subtraction of the rotation radius and the
+// sums are per pass -- each pass's sums see exactly the operations of a separate evaluation.
+template <int LAYOUT, int NP>
+__device__ __forceinline__ void lean_points(const float4* __restrict__ src, int p0, int p1, const DtDesc& dt, const Rot9& R0, const SiblingSet& ts, float delta,
+                                            const float (&coeff)[NP], f2 (&ub2)[NP][4], f2 (&lb2)[NP][4])
+{
+	const f2 delta2 = f2{delta, delta};
+	for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
+		const float4 p = src[i];
+		const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
+		const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
+		const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
+		const float qx[2] = {rx + ts.tx0, rx + ts.tx1}, qy[2] = {ry + ts.ty0, ry + ts.ty1}, qz[2] = {rz + ts.tz0, rz + ts.tz1};
+		float F[6] = {__fmaf_rn(qx[0] - dt.xmin_f, dt.scale_f, 0.5f), __fmaf_rn(qx[1] - dt.xmin_f, dt.scale_f, 0.5f),
+		              __fmaf_rn(qy[0] - dt.ymin_f, dt.scale_f, 0.5f), __fmaf_rn(qy[1] - dt.ymin_f, dt.scale_f, 0.5f),
+		              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
+		float worst = INFINITY;
+#pragma unroll
+		for (int k = 0; k < 6; k++) worst = fminf(worst, fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1));
+		int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
+		if (worst <= 0.f) {
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
+				iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
+				iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
+			}
+		}
+		const unsigned V = (unsigned)dt.V;
+		const bool inside = (unsigned)ix[0] < V && (unsigned)ix[1] < V && (unsigned)iy[0] < V && (unsigned)iy[1] < V && (unsigned)iz[0] < V && (unsigned)iz[1] < V;
+		float rho[NP];
+#pragma unroll
+		for (int q = 0; q < NP; q++) rho[q] = coeff[q] * p.w;
+		if (__all(inside)) {
+			unsigned fx[2], fy[2], fz[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				// BYTE offsets (the lean variant only runs on grids of at most 256 MB: they fit 32 bits)
+				if (LAYOUT == 0) { fx[k] = (unsigned)ix[k] << 2; fy[k] = __umul24((unsigned)iy[k], V) << 2; fz[k] = __umul24((unsigned)iz[k], V * V) << 2; }
+				else {
+					fx[k] = (((unsigned)ix[k] >> 2) << 8) | (((unsigned)ix[k] & 3u) << 2);
+					fy[k] = (__umul24((unsigned)iy[k] >> 2, (unsigned)dt.VB) << 8) | (((unsigned)iy[k] & 3u) << 4);
+					fz[k] = (__umul24((unsigned)iz[k] >> 2, (unsigned)(dt.VB * dt.VB)) << 8) | (((unsigned)iz[k] & 3u) << 6);
+				}
+			}
+			const char* gb = reinterpret_cast<const char*>(dt.grid);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const unsigned yz = fy[k & 1] + fz[k >> 1];
+				const f2 v = f2{*reinterpret_cast<const float*>(gb + (fx[0] + yz)), *reinterpret_cast<const float*>(gb + (fx[1] + yz))};
+#pragma unroll
+				for (int q = 0; q < NP; q++) {
+					const f2 mm = __builtin_elementwise_max(v - f2{rho[q], rho[q]}, f2{0.f, 0.f});
+					ub2[q][k] = ub2[q][k] + mm * mm;
+					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
+					lb2[q][k] = lb2[q][k] + dis * dis;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < NP; q++) {
+				float m[kGroup];
+				sibling_residuals<LAYOUT>(dt, R0, ts, p, rho[q], m);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const f2 mm = f2{m[2 * k], m[2 * k + 1]};
+					ub2[q][k] = ub2[q][k] + mm * mm;
+					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
+					lb2[q][k] = lb2[q][k] + dis * dis;
+				}
+			}
+		}
+	}
+}
+
+// the sums of one (expansion, chunk) work item: wave64 reduce, then the 4 wavefronts through LDS, then the item's row of the scratch block (or,
+// unsplit, the bounds themselves)
+__device__ __forceinline__ void bounds_item_store(const float (&ub)[kGroup], const float (&lb)[kGroup], int group, int chunk, int chunks, int B,
+                                                  float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, float (*red)[2 * kGroup])
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c0 = group * kGroup;
+#pragma unroll
+	for (int c = 0; c < kGroup; c++) {
+		float u = wave_sum(ub[c]), l = wave_sum(lb[c]);
+		if (lane == 0) { red[wave][c] = u; red[wave][kGroup + c] = l; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 2 * kGroup) {
+		float s = red[0][threadIdx.x];
+#pragma unroll
+		for (int w = 1; w < kBoundsThreads / 64; w++) s += red[w][threadIdx.x];
+		if (chunks == 1) {
+			int c = threadIdx.x & (kGroup - 1);
+			if (c0 + c < B) (threadIdx.x < kGroup ? ub_out : lb_out)[c0 + c] = s;
+		} else {
+			scratch[((size_t)group * chunks + chunk) * (2 * kGroup) + threadIdx.x] = s;
+		}
+	}
+}
+
+// twin test of the device-resident searches (bnbqueue.hip): the two searches of a rotation child -- upper-bound pass (coeff 0) and
+// lower-bound pass -- often list the SAME translation node in the same round (the root always, most depth-1 and depth-2 nodes of the
+// upper-bound pass).  The gathers of such a pair are identical; the lower-bound pass's item then evaluates both, the other leaves.
+struct TwinCtx { const QSearch* searches; const int* psearch; int* sh; };
+
 // work item `work` of `total` = groups*chunks: one (cube group, point chunk) pair
 template <int LAYOUT, bool LEAN>
 __device__ __forceinline__ void bounds_work(
     int work, int total, const float4* __restrict__ src, int N, const DtDesc& dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
-    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, float (*red)[2 * kGroup])
+    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, float (*red)[2 * kGroup],
+    const unsigned* __restrict__ order = nullptr, const TwinCtx tw = TwinCtx{nullptr, nullptr, nullptr})
 {
 	// XCD-aware tiling (speed only): blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns
 	// the point chunks [x*cpx, (x+1)*cpx) -- a compact spatial patch of the k-d-ordered cloud -- and
 	// walks the cube groups in order, so at any time one L2 serves gathers into the DT neighbourhood
 	// of ONE patch under nearby translations (a few MB) instead of the whole surface band.
 	int chunk, group;
-	if ((chunks & 7) == 0) {
+	if (order) {
+		// footprint-ordered items: XCD x walks the x-th eighth of the sorted list
+		const int q = total >> 3, r = total & 7, x = work & 7, s = work >> 3;
+		const unsigned t = order[(x <= r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s];
+		group = (int)(t / (unsigned)chunks);
+		chunk = (int)t - group * chunks;
+	} else if ((chunks & 7) == 0) {
 		const int cpx = chunks >> 3, xcd = work & 7, slot = work >> 3;
 		group = slot / cpx;
 		chunk = xcd * cpx + (slot - group * cpx);
@@ -291,74 +408,50 @@ __device__ __forceinline__ void bounds_work(
 		// same float expression as in the generic path below, so the results are bit-identical
 		const SiblingSet ts{cr[0].tx, cr[1].tx, cr[0].ty, cr[2].ty, cr[0].tz, cr[4].tz};
 		const float delta = cr[0].delta, coeff = cr[0].coeff;
-		// LEAN (round 3; fp32 grids that fit the Infinity Cache): one exactness test per point on the smallest margin of the six
-		// indices; a wavefront whose indices are all inside the grid fetches without per-child checks; the eight children are
-		// accumulated as four x-sibling pairs in packed fp32 -- the same operations per element, bit-identical bounds.  Bunny
-		// microbench 1.837 -> 1.791 ms per launch, full registration 42.1 -> 40.6 ms; at 1 M points / 512^3 (HBM-bound) the same
-		// code is 13 % SLOWER (53.3 -> 60.5 ms), so the launch picks it by the size of the grid.
-		f2 ub2[4], lb2[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) { ub2[k] = f2{0.f, 0.f}; lb2[k] = f2{0.f, 0.f}; }
-		const f2 delta2 = f2{delta, delta};
-		if constexpr (LEAN && LAYOUT != 2)
-		for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
-			const float4 p = src[i];
-			const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
-			const float ry = R0.r[3] * p.x + R0.r[4] * p.y + R0.r[5] * p.z;
-			const float rz = R0.r[6] * p.x + R0.r[7] * p.y + R0.r[8] * p.z;
-			const float qx[2] = {rx + ts.tx0, rx + ts.tx1}, qy[2] = {ry + ts.ty0, ry + ts.ty1}, qz[2] = {rz + ts.tz0, rz + ts.tz1};
-			float F[6] = {__fmaf_rn(qx[0] - dt.xmin_f, dt.scale_f, 0.5f), __fmaf_rn(qx[1] - dt.xmin_f, dt.scale_f, 0.5f),
-			              __fmaf_rn(qy[0] - dt.ymin_f, dt.scale_f, 0.5f), __fmaf_rn(qy[1] - dt.ymin_f, dt.scale_f, 0.5f),
-			              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
-			float worst = INFINITY;
-#pragma unroll
-			for (int k = 0; k < 6; k++) worst = fminf(worst, fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1));
-			int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
-			if (worst <= 0.f) {
-#pragma unroll
-				for (int k = 0; k < 2; k++) {
-					ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
-					iy[k] = voxel_exact(qy[k], dt.ymin, dt.scale);
-					iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
-				}
-			}
-			const unsigned V = (unsigned)dt.V;
-			const bool inside = (unsigned)ix[0] < V && (unsigned)ix[1] < V && (unsigned)iy[0] < V && (unsigned)iy[1] < V && (unsigned)iz[0] < V && (unsigned)iz[1] < V;
-			const float rho = coeff * p.w;
-			if (__all(inside)) {
-				unsigned fx[2], fy[2], fz[2];
-#pragma unroll
-				for (int k = 0; k < 2; k++) {
-					// BYTE offsets (the lean variant only runs on grids of at most 256 MB: they fit 32 bits)
-					if (LAYOUT == 0) { fx[k] = (unsigned)ix[k] << 2; fy[k] = __umul24((unsigned)iy[k], V) << 2; fz[k] = __umul24((unsigned)iz[k], V * V) << 2; }
-					else {
-						fx[k] = (((unsigned)ix[k] >> 2) << 8) | (((unsigned)ix[k] & 3u) << 2);
-						fy[k] = (__umul24((unsigned)iy[k] >> 2, (unsigned)dt.VB) << 8) | (((unsigned)iy[k] & 3u) << 4);
-						fz[k] = (__umul24((unsigned)iz[k] >> 2, (unsigned)(dt.VB * dt.VB)) << 8) | (((unsigned)iz[k] & 3u) << 6);
+		// LEAN: lean_points (above).  Bunny microbench 1.837 -> 1.791 ms per launch, full registration 42.1 -> 40.6 ms; at 1 M points / 512^3
+		// (HBM-bound) the same code is 13 % SLOWER (53.3 -> 60.5 ms), so the launch picks it by the size of the grid.
+		if constexpr (LEAN && LAYOUT != 2) {
+			// twin test (device-resident searches only): is this node also listed by the other search of the rotation child?
+			int twin = -1;
+			if (tw.searches) {
+				const int ts_ = tw.searches[tw.psearch[group]].twin;
+				if (ts_ >= 0) {
+					const int tn = tw.searches[ts_].n_parents, toff = tw.searches[ts_].parent_off;
+					if (tn > 0 && tw.searches[ts_].tile == 0) {
+						if (threadIdx.x == 0) *tw.sh = -1;
+						__syncthreads();
+						if ((int)threadIdx.x < tn) {
+							const ParentRec o = parents[toff + threadIdx.x], me = parents[group];
+							if (o.x == me.x && o.y == me.y && o.z == me.z && o.w == me.w && o.rot == me.rot && (o.coeff == 0.f) != (me.coeff == 0.f)) *tw.sh = toff + (int)threadIdx.x;
+						}
+						__syncthreads();
+						twin = *tw.sh;
 					}
 				}
-				const f2 rho2 = f2{rho, rho};
-				const char* gb = reinterpret_cast<const char*>(dt.grid);
+			}
+			if (twin >= 0 && coeff == 0.f) return;              // the lower-bound pass's item evaluates this expansion for both
+			if (twin >= 0) {
+				f2 ub2[2][4], lb2[2][4];
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const unsigned yz = fy[k & 1] + fz[k >> 1];
-					f2 v = f2{*reinterpret_cast<const float*>(gb + (fx[0] + yz)), *reinterpret_cast<const float*>(gb + (fx[1] + yz))};
-					v = v - rho2;
-					const f2 mm = __builtin_elementwise_max(v, f2{0.f, 0.f});
-					ub2[k] = ub2[k] + mm * mm;
-					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
-					lb2[k] = lb2[k] + dis * dis;
-				}
+				for (int q = 0; q < 2; q++)
+#pragma unroll
+					for (int k = 0; k < 4; k++) { ub2[q][k] = f2{0.f, 0.f}; lb2[q][k] = f2{0.f, 0.f}; }
+				const float co[2] = {coeff, 0.f};
+				lean_points<LAYOUT, 2>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
+#pragma unroll
+				for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[1][k].x; ub[2 * k + 1] = ub2[1][k].y; lb[2 * k] = lb2[1][k].x; lb[2 * k + 1] = lb2[1][k].y; }
+				bounds_item_store(ub, lb, twin, chunk, chunks, B, scratch, ub_out, lb_out, red);
+				__syncthreads();                                  // `red` is reused for the item's own sums
+#pragma unroll
+				for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[0][k].x; ub[2 * k + 1] = ub2[0][k].y; lb[2 * k] = lb2[0][k].x; lb[2 * k + 1] = lb2[0][k].y; }
 			} else {
-				float m[kGroup];
-				sibling_residuals<LAYOUT>(dt, R0, ts, p, rho, m);
+				f2 ub2[1][4], lb2[1][4];
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const f2 mm = f2{m[2 * k], m[2 * k + 1]};
-					ub2[k] = ub2[k] + mm * mm;
-					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
-					lb2[k] = lb2[k] + dis * dis;
-				}
+				for (int k = 0; k < 4; k++) { ub2[0][k] = f2{0.f, 0.f}; lb2[0][k] = f2{0.f, 0.f}; }
+				const float co[1] = {coeff};
+				lean_points<LAYOUT, 1>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
+#pragma unroll
+				for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[0][k].x; ub[2 * k + 1] = ub2[0][k].y; lb[2 * k] = lb2[0][k].x; lb[2 * k + 1] = lb2[0][k].y; }
 			}
 		}
 		else
@@ -372,10 +465,6 @@ __device__ __forceinline__ void bounds_work(
 				const float dis = fmaxf(m[c] - delta, 0.f);
 				lb[c] += dis * dis;
 			}
-		}
-		if constexpr (LEAN && LAYOUT != 2) {
-#pragma unroll
-			for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[k].x; ub[2 * k + 1] = ub2[k].y; lb[2 * k] = lb2[k].x; lb[2 * k + 1] = lb2[k].y; }
 		}
 	} else
 	for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
@@ -401,25 +490,7 @@ __device__ __forceinline__ void bounds_work(
 		}
 	}
 
-	// wave64 reduce, then 4 waves through LDS
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-	for (int c = 0; c < kGroup; c++) {
-		float u = wave_sum(ub[c]), l = wave_sum(lb[c]);
-		if (lane == 0) { red[wave][c] = u; red[wave][kGroup + c] = l; }
-	}
-	__syncthreads();
-	if (threadIdx.x < 2 * kGroup) {
-		float s = red[0][threadIdx.x];
-#pragma unroll
-		for (int w = 1; w < kBoundsThreads / 64; w++) s += red[w][threadIdx.x];
-		if (chunks == 1) {
-			int c = threadIdx.x & (kGroup - 1);
-			if (c0 + c < B) (threadIdx.x < kGroup ? ub_out : lb_out)[c0 + c] = s;
-		} else {
-			scratch[((size_t)group * chunks + chunk) * (2 * kGroup) + threadIdx.x] = s;
-		}
-	}
+	bounds_item_store(ub, lb, group, chunk, chunks, B, scratch, ub_out, lb_out, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,10 +860,10 @@ template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
-    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
+    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, const unsigned* __restrict__ order = nullptr)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
-	bounds_work<LAYOUT, LEAN>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red);
+	bounds_work<LAYOUT, LEAN>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red, order);
 }
 
 // The same evaluation for a batch whose size only the DEVICE knows (the device-resident BnB queues, bnbqueue.hip):
@@ -809,10 +880,12 @@ template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots, const ParentRec* __restrict__ parents,
     const int* __restrict__ d_groups, int* __restrict__ work8, int* __restrict__ d_chunks, float* __restrict__ scratch, float* __restrict__ ub_out,
-    float* __restrict__ lb_out)
+    float* __restrict__ lb_out, const QSearch* __restrict__ searches, const int* __restrict__ parent_search)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
 	__shared__ int next_item[2];
+	__shared__ int twin_sh;
+	const TwinCtx twin{LEAN ? searches : nullptr, parent_search, &twin_sh};
 	const int ngroups = *d_groups;
 	if (ngroups <= 0) return;
 	int groups, chunks, chunk_pts;
@@ -828,7 +901,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	while (item * stride + slot < total) {
 		if (threadIdx.x == 0) next_item[buf ^ 1] = atomicAdd(ctr, 1);   // in flight while this item is evaluated
 		bounds_work<LAYOUT, LEAN>(item * stride + slot, total, src, N, dt, rots, nullptr, parents, ngroups * kGroup, groups, chunks, chunk_pts, scratch, ub_out,
-		                    lb_out, red);
+		                    lb_out, red, nullptr, twin);
 		__syncthreads();                                                 // `red` is reused by the next item; next_item is published
 		buf ^= 1;
 		item = next_item[buf];
@@ -1033,8 +1106,10 @@ size_t bounds_queue_scratch_floats(int max_groups)
 }
 
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
-                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream)
+                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream,
+                               const QSearch* searches, const int* parent_search)
 {
+	if (!parent_search) searches = nullptr;
 	if (max_groups <= 0 || N <= 0) return hipSuccess;
 	if (inliers < N) {
 		// trimmed form: one workgroup per expansion, the surplus workgroups of the fixed grid leave at once
@@ -1045,10 +1120,108 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 		return hipGetLastError();
 	}
 	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
-	else if (dt.layout == 1 && bounds_lean(dt)) hipLaunchKernelGGL((bounds_queue_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
-	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
-	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
+	else if (dt.layout == 1 && bounds_lean(dt)) hipLaunchKernelGGL((bounds_queue_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
+	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
+	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
+	return hipGetLastError();
+}
+
+// ---- EXPERIMENT (GOICP_SORT_CHUNK=<points per chunk>): work items ordered by where their gathers land ----
+__global__ __launch_bounds__(256) void chunk_centroid_kernel(const float4* __restrict__ src, int N, int chunk_pts, float4* __restrict__ cen)
+{
+	__shared__ float red[4][3];
+	const int p0 = blockIdx.x * chunk_pts, p1 = min(p0 + chunk_pts, N);
+	float sx = 0.f, sy = 0.f, sz = 0.f;
+	for (int i = p0 + (int)threadIdx.x; i < p1; i += 256) { const float4 p = src[i]; sx += p.x; sy += p.y; sz += p.z; }
+	sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+	if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; red[threadIdx.x >> 6][2] = sz; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const float n = (float)max(p1 - p0, 1);
+		cen[blockIdx.x] = make_float4((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / n, (red[0][1] + red[1][1] + red[2][1] + red[3][1]) / n,
+		                              (red[0][2] + red[1][2] + red[2][2] + red[3][2]) / n, 0.f);
+	}
+}
+__global__ void task_key_kernel(const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, const Rot9* __restrict__ rots, const float4* __restrict__ cen,
+                                int B, int groups, int chunks, DtDesc dt, int shift, unsigned* __restrict__ keys, unsigned* __restrict__ hist)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= groups * chunks) return;
+	const int group = t / chunks, chunk = t - group * chunks;
+	float cx, cy, cz; int rot;
+	if (parents) { const ParentRec p = parents[group]; cx = p.x + 0.5f * p.w; cy = p.y + 0.5f * p.w; cz = p.z + 0.5f * p.w; rot = p.rot; }
+	else {
+		const CubeRec a = cubes[group * kGroup], b = cubes[min(group * kGroup + kGroup - 1, B - 1)];
+		cx = 0.5f * (a.tx + b.tx); cy = 0.5f * (a.ty + b.ty); cz = 0.5f * (a.tz + b.tz); rot = a.rot;
+	}
+	const Rot9 R = rots[rot];
+	const float4 c = cen[chunk];
+	const float q[3] = {R.r[0] * c.x + R.r[1] * c.y + R.r[2] * c.z + cx - dt.xmin_f, R.r[3] * c.x + R.r[4] * c.y + R.r[5] * c.z + cy - dt.ymin_f,
+	                    R.r[6] * c.x + R.r[7] * c.y + R.r[8] * c.z + cz - dt.zmin_f};
+	unsigned key = 0;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const unsigned v = (unsigned)min(max((int)(q[k] * dt.scale_f), 0), dt.V - 1) >> shift;
+#pragma unroll
+		for (int b = 0; b < 5; b++) key |= ((v >> b) & 1u) << (3 * b + k);
+	}
+	keys[t] = key;
+	atomicAdd(&hist[key], 1u);
+}
+__global__ void task_scatter_kernel(const unsigned* __restrict__ keys, int T, unsigned* __restrict__ offs, unsigned* __restrict__ order)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < T) order[atomicAdd(&offs[keys[t]], 1u)] = (unsigned)t;
+}
+static int sort_chunk_env()
+{
+	static int v = -1;
+	if (v < 0) { const char* e = getenv("GOICP_SORT_CHUNK"); v = e ? atoi(e) : 0; }
+	return v;
+}
+static hipError_t launch_bounds_sorted(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
+                                       int B, float* ub, float* lb, hipStream_t stream, int chunk_pts)
+{
+	static float4* cen = nullptr; static unsigned *hist = nullptr, *order = nullptr, *keys = nullptr; static float* scratch = nullptr;
+	static size_t cap = 0; static const void* cen_src = nullptr; static int cen_cp = 0;
+	constexpr int kBins = 1 << 15;
+	chunk_pts = (chunk_pts + kBoundsThreads - 1) / kBoundsThreads * kBoundsThreads;
+	const int groups = (B + kGroup - 1) / kGroup, chunks = (N + chunk_pts - 1) / chunk_pts, T = groups * chunks;
+	if (!hist) { if (hipMalloc(&hist, sizeof(unsigned) * kBins) != hipSuccess) return hipErrorOutOfMemory; }
+	if ((size_t)T > cap) {
+		hipDeviceSynchronize();
+		hipFree(order); hipFree(keys); hipFree(scratch);
+		cap = (size_t)T * 2;
+		if (hipMalloc(&order, 4 * cap) || hipMalloc(&keys, 4 * cap) || hipMalloc(&scratch, sizeof(float) * 2 * kGroup * cap)) return hipErrorOutOfMemory;
+	}
+	if (cen_src != src || cen_cp != chunk_pts) {
+		hipDeviceSynchronize();
+		hipFree(cen);
+		if (hipMalloc(&cen, sizeof(float4) * chunks)) return hipErrorOutOfMemory;
+		hipLaunchKernelGGL(chunk_centroid_kernel, dim3(chunks), dim3(256), 0, stream, src, N, chunk_pts, cen);
+		cen_src = src; cen_cp = chunk_pts;
+	}
+	int shift = 0;
+	while (((dt.V - 1) >> shift) >= 32) shift++;
+	static int shift_env = -1;
+	if (shift_env < 0) { const char* e = getenv("GOICP_SORT_SHIFT"); shift_env = e ? atoi(e) : 0; }
+	if (shift_env > shift) shift = shift_env;
+	hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * kBins, stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(task_key_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, cubes, parents, rots, cen, B, groups, chunks, dt, shift, keys, hist);
+	hipLaunchKernelGGL(cube_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, kBins);
+	hipLaunchKernelGGL(task_scatter_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, keys, T, hist, order);
+	dim3 grid(T), block(kBoundsThreads);
+	if (dt.layout == 1 && bounds_lean(dt))
+		hipLaunchKernelGGL((bounds_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb, order);
+	else if (dt.layout == 1)
+		hipLaunchKernelGGL((bounds_kernel<1, false>), grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb, order);
+	else return hipErrorInvalidValue;
+	if (chunks > 1) {
+		const int t = groups * 2 * kGroup;
+		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, B, groups, chunks, ub, lb);
+	}
 	return hipGetLastError();
 }
 
@@ -1056,6 +1229,7 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream)
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
+	if (sort_chunk_env() > 0 && dt.layout == 1) return launch_bounds_sorted(src, N, dt, rots, cubes, parents, B, ub, lb, stream, sort_chunk_env());
 	int groups, chunks, chunk_pts;
 	bounds_shape(B, N, &groups, &chunks, &chunk_pts);
 	dim3 grid(groups * chunks), block(kBoundsThreads);

@@ -106,6 +106,9 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 	float min_ub;                   // smallest upper bound of any child this search evaluated (whether or not it beat the incumbent)
 	int32_t deep;                   // diagnostics: the last selection lay within the tile spread
 	int32_t stale;                  // rounds since this search's incumbent last improved (QParams::stale_widen)
+	int32_t twin;                   // the other search of the same rotation child (upper-bound pass <-> lower-bound pass), -1: none.  When both list
+	                                // the SAME translation node in a round, the lower-bound pass's work items evaluate it for both (one gather, two
+	                                // subtractions): bounds_work, device.hip
 };
 struct TileSeg { int32_t off, n, rot; };   // tile list: a search's expansions parents[off .. off+n), n <= 64, one rotation
 struct QCtl {
@@ -143,18 +146,20 @@ struct QParams {
 	float tile_stats_scale;         // voxels per world unit
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
-struct QInit { int32_t slot; float best; float coeff; int32_t rot; };
+struct QInit { int32_t slot; float best; float coeff; int32_t rot; int32_t twin; };
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream);
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile = nullptr);
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile = nullptr,
+                            int* parent_search = nullptr);       // parent_search[g] = the search that listed expansion g of the direct list (for the twin test)
 // bounds of the tile list of round `parity` (segment count known to the device only); fixed grid
 hipError_t launch_bounds_tile_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const QTile& tile, QCtl* ctl, int parity, hipStream_t stream);
 size_t bounds_tile_queue_scratch_floats(int max_groups);
 // bounds of the 8 children of the *d_groups expansions in `parents` (count known to the device only); max_groups sizes the grids
 // (d_chunks: QCtl::chunks -- the evaluation leaves chunk partials in `scratch` when it splits the cloud, and says so there)
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
-                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream);
+                               int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream,
+                               const QSearch* searches = nullptr, const int* parent_search = nullptr);   // both given: twin expansions are evaluated once
 size_t bounds_queue_scratch_floats(int max_groups);
 // LDS-staged DT tiles for the deep expansions of a search (device.hip bounds_tile_kernel): nseg segments of n <= 64 expansions,
 // segs = nseg x {int off, int n, int rot}; stats (may be null): [0] sub-patches staged, [1] sub-patches whose box did not fit

@@ -473,7 +473,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			// full-size read-back of the search records, once, here
 			const QParams qp = queue_params();
 			flow_reset();
-			h_qinit_[0] = QInit{0, 0.f, 0.f, 0};
+			h_qinit_[0] = QInit{0, 0.f, 0.f, 0, -1};
 			std::memcpy(h_rots_[0].r, I9, sizeof(I9));
 			HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * (kFlowSearches / 2), hipMemcpyHostToDevice, stream_));
 			HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * kFlowSearches, hipMemcpyHostToDevice, stream_));
@@ -509,12 +509,12 @@ void Engine::release()
 	if (stream_ && hipGetDevice(&prev) == hipSuccess && prev != dev_) hipSetDevice(dev_); else prev = -1;
 	if (stream_) hipStreamSynchronize(stream_);
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
-	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
+	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
 	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
 	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
 	hipFree(d_qinit_); hipHostFree(h_qinit_); d_qinit_ = nullptr; h_qinit_ = nullptr;
-	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
+	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr; d_qpsearch_[0] = d_qpsearch_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_); hipFree(d_dt16_); d_dt16_ = nullptr;
 	hipFree(d_nn_ids_); d_nn_ids_ = nullptr;
@@ -1025,17 +1025,18 @@ void Engine::ensure_queues(size_t nsearch)
 	size_t cap = std::max<size_t>(cap_qsearch_, p_.wide_children ? (size_t)16 * (size_t)std::max(1, p_.rot_batch) : 16);
 	while (cap < nsearch) cap *= 2;
 	HIPCHK(hipStreamSynchronize(stream_));
-	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]);
+	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_);
 	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
 	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
-	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr;
+	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr; d_qpsearch_[0] = d_qpsearch_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
 	const size_t max_groups = cap * kQueueMaxPop;
 	HIPCHK(hipMalloc(&d_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipHostMalloc(&h_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipMalloc(&d_qnodes_, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
 	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qparents_[k], sizeof(ParentRec) * max_groups));
+	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qpsearch_[k], sizeof(int) * max_groups));
 	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups)));
@@ -1072,6 +1073,17 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		QSearch& q = h_qsearch_[i];
 		std::memset(&q, 0, sizeof(q));
 		q.best = searches[i]->best; q.coeff = searches[i]->coeff; q.rot = searches[i]->rot_slot;
+		q.twin = -1;
+	}
+	// the two searches of a rotation child (same rotation slot, one upper-bound pass with coeff 0, one lower-bound pass): each other's twin
+	if (p_.twin_fusion && d_qpsearch_[0]) {
+		std::vector<int> first(nrot, -1);
+		for (size_t i = 0; i < S; i++) {
+			const int r = searches[i]->rot_slot;
+			if (first[r] < 0) { first[r] = (int)i; continue; }
+			const int j = first[r];
+			if (j >= 0 && h_qsearch_[j].twin < 0 && (h_qsearch_[j].coeff == 0.f) != (h_qsearch_[i].coeff == 0.f)) { h_qsearch_[j].twin = (int)i; h_qsearch_[i].twin = j; }
+		}
 	}
 	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * S, hipMemcpyHostToDevice, stream_));
 	QParams qp = queue_params();
@@ -1081,6 +1093,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	// the tile list: always on (lds_tiles 1), or -- the default -- only for the rounds that follow a read-back in which searches
 	// qualified (QCtl::tile_hint moved): shallow batches, i.e. every default registration, never pay for the extra launch
 	const bool tiles = qtile_.ub != nullptr;
+	const bool twins = p_.twin_fusion && d_qpsearch_[0] != nullptr;
 	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
 	tile_hint_seen_ = 0;
 	while (true) {
@@ -1088,9 +1101,10 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		int last = 0;
 		const int max_groups = (int)(S * (size_t)qp.K);
 		for (int r = 0; r < chunk; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr));
+			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr,
+			                        twins ? d_qpsearch_[parity] : nullptr));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
-			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr));
 			if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
 			last = parity;
 			parity ^= 1;
@@ -1590,8 +1604,8 @@ int Engine::flow_step(int max_rot_pops)
 					f.s_ub = free_search_.back(); free_search_.pop_back();
 					f.s_lb = free_search_.back(); free_search_.pop_back();
 					std::memcpy(h_rots_[f.rot_slot].r, k.R, sizeof(float) * 9);
-					h_qinit_[n++] = QInit{f.s_ub, opt_err_, 0.f, f.rot_slot};
-					h_qinit_[n++] = QInit{f.s_lb, opt_err_, rot_coeff(k.node.l), f.rot_slot};
+					h_qinit_[n++] = QInit{f.s_ub, opt_err_, 0.f, f.rot_slot, -1};
+					h_qinit_[n++] = QInit{f.s_lb, opt_err_, rot_coeff(k.node.l), f.rot_slot, -1};
 					q_hi_ = std::max(q_hi_, std::max(f.s_ub, f.s_lb) + 1);
 					flights_.push_back(f);
 				}

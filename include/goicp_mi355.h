@@ -160,6 +160,10 @@ typedef struct goicp_params {
 	                          * target point is a valid candidate; ties still go to the lowest index).  0: the DT bound */
 	float ub_share;          /* widened search: on top of the rot_batch parents drawn by smallest lower bound, this fraction more are drawn per batch by the
 	                          * smallest upper bound seen inside them (needs ub_tiebreak = 1; default 0 = none: measured slower) */
+	int32_t twin_fusion;     /* 1 (default): the two inner searches of a rotation child -- GoICP::InnerBnB without and with the rotation uncertainty
+	                          * (jly_goicp.cpp:494 and :532), same rotated cloud -- run in lock-step; when both list the SAME translation node in a
+	                          * round its 8 children are gathered from the distance transform ONCE and the two passes' sums are formed from the
+	                          * same fetched values (bit-identical to separate evaluations).  0: every listed node is evaluated on its own */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);

@@ -19,6 +19,7 @@
 //   dt_*                 exact Euclidean DT build (seed, three separable min-plus passes, sqrt/scale)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <cmath>
@@ -353,6 +354,8 @@ __device__ __forceinline__ void bounds_item_store(const float (&ub)[kGroup], con
 // lower-bound pass -- often list the SAME translation node in the same round (the root always, most depth-1 and depth-2 nodes of the
 // upper-bound pass).  The gathers of such a pair are identical; the lower-bound pass's item then evaluates both, the other leaves.
 struct TwinCtx { const QSearch* searches; const int* psearch; int* sh; };
+// a round of at least min_groups expansions walks its items in footprint order (launch_queue_sort below)
+__device__ __forceinline__ bool qsort_on(const QSort& qs, int ngroups) { return qs.order != nullptr && ngroups >= qs.min_groups; }
 
 // work item `work` of `total` = groups*chunks: one (cube group, point chunk) pair
 template <int LAYOUT, bool LEAN>
@@ -751,6 +754,7 @@ hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const 
 
 // the lean sibling path pays while the grid is cache-resident (<= the 256 MB Infinity Cache), not when the launch is HBM-bound
 static inline bool bounds_lean(const DtDesc& dt) { return (size_t)dt.V * dt.V * dt.V * sizeof(float) <= ((size_t)256 << 20); }
+bool bounds_uses_lean(const DtDesc& dt) { return dt.layout == 1 && bounds_lean(dt); }
 constexpr int kTileQueueGrid = 256 * (160 * 1024 / (kTileFloats * 4 + 2048));   // as many workgroups per CU as their LDS allows (32 KB tiles: four)
 size_t bounds_tile_queue_scratch_floats(int max_groups)
 {
@@ -860,10 +864,10 @@ template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
     const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, int B, int groups, int chunks, int chunk_pts,
-    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out, const unsigned* __restrict__ order = nullptr)
+    float* __restrict__ scratch, float* __restrict__ ub_out, float* __restrict__ lb_out)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
-	bounds_work<LAYOUT, LEAN>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red, order);
+	bounds_work<LAYOUT, LEAN>(blockIdx.x, gridDim.x, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub_out, lb_out, red);
 }
 
 // The same evaluation for a batch whose size only the DEVICE knows (the device-resident BnB queues, bnbqueue.hip):
@@ -880,7 +884,7 @@ template <int LAYOUT, bool LEAN = false>
 __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
     const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots, const ParentRec* __restrict__ parents,
     const int* __restrict__ d_groups, int* __restrict__ work8, int* __restrict__ d_chunks, float* __restrict__ scratch, float* __restrict__ ub_out,
-    float* __restrict__ lb_out, const QSearch* __restrict__ searches, const int* __restrict__ parent_search)
+    float* __restrict__ lb_out, const QSearch* __restrict__ searches, const int* __restrict__ parent_search, QSort qs)
 {
 	__shared__ float red[kBoundsThreads / 64][2 * kGroup];
 	__shared__ int next_item[2];
@@ -889,10 +893,12 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	const int ngroups = *d_groups;
 	if (ngroups <= 0) return;
 	int groups, chunks, chunk_pts;
-	bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
+	const bool sorted = qsort_on(qs, ngroups);
+	if (sorted) { groups = ngroups; chunks = qs.chunks; chunk_pts = qs.chunk_pts; }
+	else bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
 	if (blockIdx.x == 0 && threadIdx.x == 0) *d_chunks = chunks;          // > 1: the next round's digest adds the chunk partials up
 	const int total = groups * chunks;
-	const bool per_xcd = (total & 7) == 0;
+	const bool per_xcd = sorted || (total & 7) == 0;
 	const int slot = per_xcd ? (int)(blockIdx.x & 7) : 0, stride = per_xcd ? 8 : 1;
 	int* ctr = work8 + slot;
 	if (threadIdx.x == 0) next_item[0] = atomicAdd(ctr, 1);
@@ -901,7 +907,7 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	while (item * stride + slot < total) {
 		if (threadIdx.x == 0) next_item[buf ^ 1] = atomicAdd(ctr, 1);   // in flight while this item is evaluated
 		bounds_work<LAYOUT, LEAN>(item * stride + slot, total, src, N, dt, rots, nullptr, parents, ngroups * kGroup, groups, chunks, chunk_pts, scratch, ub_out,
-		                    lb_out, red, nullptr, twin);
+		                    lb_out, red, sorted ? qs.order : nullptr, twin);
 		__syncthreads();                                                 // `red` is reused by the next item; next_item is published
 		buf ^= 1;
 		item = next_item[buf];
@@ -1099,17 +1105,20 @@ size_t bounds_scratch_floats(int B, int N, int* groups_out, int* chunks_out)
 	return (size_t)g * c * 2 * kGroup;
 }
 
-size_t bounds_queue_scratch_floats(int max_groups)
+size_t bounds_queue_scratch_floats(int max_groups, int sorted_chunks)
 {
-	// groups x chunks partial rows: chunks <= 8 + 1024/groups (bounds_shape), so groups*chunks <= 8*groups + 4096 (margin included)
-	return (size_t)2 * kGroup * (8 * (size_t)max_groups + 4096);
+	// groups x chunks partial rows: chunks <= 8 + 1024/groups (bounds_shape), so groups*chunks <= 8*groups + 4096 (margin included);
+	// footprint-ordered rounds cut the cloud into sorted_chunks chunks
+	return (size_t)2 * kGroup * ((size_t)std::max(8, sorted_chunks) * (size_t)max_groups + 4096);
 }
 
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
                                int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream,
-                               const QSearch* searches, const int* parent_search)
+                               const QSearch* searches, const int* parent_search, const QSort* qsort)
 {
 	if (!parent_search) searches = nullptr;
+	QSort qs{};
+	if (qsort && dt.layout == 1 && bounds_lean(dt) && inliers >= N) qs = *qsort;
 	if (max_groups <= 0 || N <= 0) return hipSuccess;
 	if (inliers < N) {
 		// trimmed form: one workgroup per expansion, the surplus workgroups of the fixed grid leave at once
@@ -1120,14 +1129,26 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 		return hipGetLastError();
 	}
 	const dim3 grid(2048), block(kBoundsThreads);                        // 8 workgroups per CU, a multiple of 8 (XCD slots)
-	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
-	else if (dt.layout == 1 && bounds_lean(dt)) hipLaunchKernelGGL((bounds_queue_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
-	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
-	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search);
+	if (dt.layout == 0) hipLaunchKernelGGL(bounds_queue_kernel<0>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search, qs);
+	else if (dt.layout == 1 && bounds_lean(dt)) hipLaunchKernelGGL((bounds_queue_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search, qs);
+	else if (dt.layout == 1) hipLaunchKernelGGL(bounds_queue_kernel<1>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search, qs);
+	else hipLaunchKernelGGL(bounds_queue_kernel<2>, grid, block, 0, stream, src, N, dt, rots, parents, d_groups, d_work8, d_chunks, scratch, ub, lb, searches, parent_search, qs);
 	return hipGetLastError();
 }
 
-// ---- EXPERIMENT (GOICP_SORT_CHUNK=<points per chunk>): work items ordered by where their gathers land ----
+// ------------------------------------------------------------------------------------------------
+// Footprint-ordered work items (round 3).  In the first rounds of a rotation batch every search expands whole levels of the
+// translation tree: hundreds of rotations x all the cubes of a level, i.e. every rotation stamps the cloud all over the grid and
+// sweeps the whole distance transform once.  Walked in search order, the items an XCD runs at any time gather from everywhere, its
+// 4 MB L2 holds nothing for the next one, and the round runs at the Infinity Cache's bandwidth (a 128-byte line for every few
+// 4-byte lookups; 75-110 CU cycles per gather against 37 when the lines are found in L2).  So for large rounds the (expansion, chunk)
+// items are bucketed by WHERE their gathers land -- the Morton cell (16 voxels) of R * centroid(chunk) + centre(parent cube) -- with a
+// counting sort (key + histogram, scan, scatter), XCD x walks the x-th eighth of the sorted list, and the cloud is cut into smaller
+// chunks (2 048 points: a ~64-voxel patch) so that an item's footprint is compact.  The order changes no bound (an item's sums go to
+// its own row); only the chunk count differs from the unsorted launch shape, i.e. the order in which a cube's per-chunk sums are added.
+// Measured (tools/round_probe.py, bunny, 230 rotations, both passes): children of level 2 1.22 -> 1.04 ms, of level 3 8.87 -> 6.81 ms.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSortBins = 1 << 15;                // 5 bits per axis
 __global__ __launch_bounds__(256) void chunk_centroid_kernel(const float4* __restrict__ src, int N, int chunk_pts, float4* __restrict__ cen)
 {
 	__shared__ float red[4][3];
@@ -1143,85 +1164,74 @@ __global__ __launch_bounds__(256) void chunk_centroid_kernel(const float4* __res
 		                              (red[0][2] + red[1][2] + red[2][2] + red[3][2]) / n, 0.f);
 	}
 }
-__global__ void task_key_kernel(const CubeRec* __restrict__ cubes, const ParentRec* __restrict__ parents, const Rot9* __restrict__ rots, const float4* __restrict__ cen,
-                                int B, int groups, int chunks, DtDesc dt, int shift, unsigned* __restrict__ keys, unsigned* __restrict__ hist)
+hipError_t launch_chunk_centroids(const float4* src, int N, int chunk_pts, float4* cen, hipStream_t stream)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= groups * chunks) return;
-	const int group = t / chunks, chunk = t - group * chunks;
-	float cx, cy, cz; int rot;
-	if (parents) { const ParentRec p = parents[group]; cx = p.x + 0.5f * p.w; cy = p.y + 0.5f * p.w; cz = p.z + 0.5f * p.w; rot = p.rot; }
-	else {
-		const CubeRec a = cubes[group * kGroup], b = cubes[min(group * kGroup + kGroup - 1, B - 1)];
-		cx = 0.5f * (a.tx + b.tx); cy = 0.5f * (a.ty + b.ty); cz = 0.5f * (a.tz + b.tz); rot = a.rot;
-	}
-	const Rot9 R = rots[rot];
-	const float4 c = cen[chunk];
-	const float q[3] = {R.r[0] * c.x + R.r[1] * c.y + R.r[2] * c.z + cx - dt.xmin_f, R.r[3] * c.x + R.r[4] * c.y + R.r[5] * c.z + cy - dt.ymin_f,
-	                    R.r[6] * c.x + R.r[7] * c.y + R.r[8] * c.z + cz - dt.zmin_f};
-	unsigned key = 0;
+	const int chunks = (N + chunk_pts - 1) / chunk_pts;
+	hipLaunchKernelGGL(chunk_centroid_kernel, dim3(chunks), dim3(256), 0, stream, src, N, chunk_pts, cen);
+	return hipGetLastError();
+}
+__global__ void task_key_kernel(const ParentRec* __restrict__ parents, const Rot9* __restrict__ rots, const int* __restrict__ d_groups, QSort qs, DtDesc dt)
+{
+	const int ngroups = *d_groups;
+	if (!qsort_on(qs, ngroups)) return;
+	const int T = ngroups * qs.chunks;
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+		const int group = t / qs.chunks, chunk = t - group * qs.chunks;
+		const ParentRec p = parents[group];
+		const Rot9 R = rots[p.rot];
+		const float4 c = qs.cen[chunk];
+		const float h = 0.5f * p.w;
+		const float q[3] = {R.r[0] * c.x + R.r[1] * c.y + R.r[2] * c.z + p.x + h - dt.xmin_f, R.r[3] * c.x + R.r[4] * c.y + R.r[5] * c.z + p.y + h - dt.ymin_f,
+		                    R.r[6] * c.x + R.r[7] * c.y + R.r[8] * c.z + p.z + h - dt.zmin_f};
+		unsigned key = 0;
 #pragma unroll
-	for (int k = 0; k < 3; k++) {
-		const unsigned v = (unsigned)min(max((int)(q[k] * dt.scale_f), 0), dt.V - 1) >> shift;
+		for (int k = 0; k < 3; k++) {
+			const unsigned v = (unsigned)min(max((int)(q[k] * dt.scale_f), 0), dt.V - 1) >> qs.shift;
 #pragma unroll
-		for (int b = 0; b < 5; b++) key |= ((v >> b) & 1u) << (3 * b + k);
+			for (int b = 0; b < 5; b++) key |= ((v >> b) & 1u) << (3 * b + k);
+		}
+		qs.keys[t] = key;
+		atomicAdd(&qs.hist[key], 1u);
 	}
-	keys[t] = key;
-	atomicAdd(&hist[key], 1u);
 }
-__global__ void task_scatter_kernel(const unsigned* __restrict__ keys, int T, unsigned* __restrict__ offs, unsigned* __restrict__ order)
+__global__ void task_scatter_kernel(const int* __restrict__ d_groups, QSort qs)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < T) order[atomicAdd(&offs[keys[t]], 1u)] = (unsigned)t;
+	const int ngroups = *d_groups;
+	if (!qsort_on(qs, ngroups)) return;
+	const int T = ngroups * qs.chunks;
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x)
+		qs.order[atomicAdd(&qs.hist[qs.keys[t]], 1u)] = (unsigned)t;          // order inside a bucket is arbitrary: no bound depends on it
 }
-static int sort_chunk_env()
+__global__ __launch_bounds__(1024) void task_scan_kernel(const int* __restrict__ d_groups, QSort qs)
 {
-	static int v = -1;
-	if (v < 0) { const char* e = getenv("GOICP_SORT_CHUNK"); v = e ? atoi(e) : 0; }
-	return v;
+	__shared__ unsigned wtot[16];
+	if (!qsort_on(qs, *d_groups)) return;
+	constexpr int per = kSortBins / 1024;
+	const int b0 = threadIdx.x * per;
+	unsigned local = 0;
+	for (int k = 0; k < per; k++) local += qs.hist[b0 + k];
+	unsigned incl = local;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
+	if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	unsigned before = 0;
+	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wtot[w];
+	unsigned run = before + incl - local;
+	for (int k = 0; k < per; k++) { const unsigned c = qs.hist[b0 + k]; qs.hist[b0 + k] = run; run += c; }
 }
-static hipError_t launch_bounds_sorted(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const CubeRec* cubes, const ParentRec* parents,
-                                       int B, float* ub, float* lb, hipStream_t stream, int chunk_pts)
+int qsort_shift(int V) { int s = 0; while (((V - 1) >> s) >= 32) s++; return s; }   // 5 bits per axis: 16-voxel cells at V = 300 and 512
+size_t qsort_hist_bytes() { return sizeof(unsigned) * kSortBins; }
+// orders the items of the round whose expansions bnb_queue_kernel has just listed (count on the device); a round below qs.min_groups is left alone
+hipError_t launch_queue_sort(const ParentRec* parents, const Rot9* rots, const int* d_groups, int max_groups, const QSort& qs, const DtDesc& dt, hipStream_t stream)
 {
-	static float4* cen = nullptr; static unsigned *hist = nullptr, *order = nullptr, *keys = nullptr; static float* scratch = nullptr;
-	static size_t cap = 0; static const void* cen_src = nullptr; static int cen_cp = 0;
-	constexpr int kBins = 1 << 15;
-	chunk_pts = (chunk_pts + kBoundsThreads - 1) / kBoundsThreads * kBoundsThreads;
-	const int groups = (B + kGroup - 1) / kGroup, chunks = (N + chunk_pts - 1) / chunk_pts, T = groups * chunks;
-	if (!hist) { if (hipMalloc(&hist, sizeof(unsigned) * kBins) != hipSuccess) return hipErrorOutOfMemory; }
-	if ((size_t)T > cap) {
-		hipDeviceSynchronize();
-		hipFree(order); hipFree(keys); hipFree(scratch);
-		cap = (size_t)T * 2;
-		if (hipMalloc(&order, 4 * cap) || hipMalloc(&keys, 4 * cap) || hipMalloc(&scratch, sizeof(float) * 2 * kGroup * cap)) return hipErrorOutOfMemory;
-	}
-	if (cen_src != src || cen_cp != chunk_pts) {
-		hipDeviceSynchronize();
-		hipFree(cen);
-		if (hipMalloc(&cen, sizeof(float4) * chunks)) return hipErrorOutOfMemory;
-		hipLaunchKernelGGL(chunk_centroid_kernel, dim3(chunks), dim3(256), 0, stream, src, N, chunk_pts, cen);
-		cen_src = src; cen_cp = chunk_pts;
-	}
-	int shift = 0;
-	while (((dt.V - 1) >> shift) >= 32) shift++;
-	static int shift_env = -1;
-	if (shift_env < 0) { const char* e = getenv("GOICP_SORT_SHIFT"); shift_env = e ? atoi(e) : 0; }
-	if (shift_env > shift) shift = shift_env;
-	hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * kBins, stream);
+	if (!qs.order || max_groups < qs.min_groups) return hipSuccess;
+	hipError_t e = hipMemsetAsync(qs.hist, 0, sizeof(unsigned) * kSortBins, stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(task_key_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, cubes, parents, rots, cen, B, groups, chunks, dt, shift, keys, hist);
-	hipLaunchKernelGGL(cube_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, kBins);
-	hipLaunchKernelGGL(task_scatter_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, keys, T, hist, order);
-	dim3 grid(T), block(kBoundsThreads);
-	if (dt.layout == 1 && bounds_lean(dt))
-		hipLaunchKernelGGL((bounds_kernel<1, true>), grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb, order);
-	else if (dt.layout == 1)
-		hipLaunchKernelGGL((bounds_kernel<1, false>), grid, block, 0, stream, src, N, dt, rots, cubes, parents, B, groups, chunks, chunk_pts, scratch, ub, lb, order);
-	else return hipErrorInvalidValue;
-	if (chunks > 1) {
-		const int t = groups * 2 * kGroup;
-		hipLaunchKernelGGL(bounds_finalize, dim3((t + 255) / 256), dim3(256), 0, stream, scratch, B, groups, chunks, ub, lb);
-	}
+	const int blocks = (int)std::min<size_t>(((size_t)max_groups * qs.chunks + 255) / 256, 2048);
+	hipLaunchKernelGGL(task_key_kernel, dim3(blocks), dim3(256), 0, stream, parents, rots, d_groups, qs, dt);
+	hipLaunchKernelGGL(task_scan_kernel, dim3(1), dim3(1024), 0, stream, d_groups, qs);
+	hipLaunchKernelGGL(task_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_groups, qs);
 	return hipGetLastError();
 }
 
@@ -1229,7 +1239,6 @@ hipError_t launch_bounds(const float4* src, int N, const DtDesc& dt, const Rot9*
                          int B, float* scratch, float* ub, float* lb, hipStream_t stream)
 {
 	if (B <= 0 || N <= 0) return hipSuccess;
-	if (sort_chunk_env() > 0 && dt.layout == 1) return launch_bounds_sorted(src, N, dt, rots, cubes, parents, B, ub, lb, stream, sort_chunk_env());
 	int groups, chunks, chunk_pts;
 	bounds_shape(B, N, &groups, &chunks, &chunk_pts);
 	dim3 grid(groups * chunks), block(kBoundsThreads);

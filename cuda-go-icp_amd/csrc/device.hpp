@@ -146,6 +146,16 @@ struct QParams {
 	float tile_stats_scale;         // voxels per world unit
 };
 hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QParams& qp, QCtl* ctl, hipStream_t stream);
+// footprint-ordered work items of the bound evaluation (device.hip): buffers and shape of the sorted launch
+struct QSort {
+	const float4* cen;              // centroid of every chunk of chunk_pts points
+	unsigned* keys;                 // per item: Morton cell of the item's footprint centre
+	unsigned* hist;                 // 32 768 bins
+	unsigned* order;                // the items in bucket order; nullptr = feature off
+	int32_t chunk_pts, chunks;      // the sorted launch shape
+	int32_t min_groups;             // smaller rounds keep the unsorted shape
+	int32_t shift;                  // voxel -> cell
+};
 struct QInit { int32_t slot; float best; float coeff; int32_t rot; int32_t twin; };
 hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list, int n, const QParams& qp, hipStream_t stream);
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
@@ -159,8 +169,14 @@ size_t bounds_tile_queue_scratch_floats(int max_groups);
 // (d_chunks: QCtl::chunks -- the evaluation leaves chunk partials in `scratch` when it splits the cloud, and says so there)
 hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const int* d_groups,
                                int* d_work8, int* d_chunks, int max_groups, int inliers, float* scratch, float* ub, float* lb, hipStream_t stream,
-                               const QSearch* searches = nullptr, const int* parent_search = nullptr);   // both given: twin expansions are evaluated once
-size_t bounds_queue_scratch_floats(int max_groups);
+                               const QSearch* searches = nullptr, const int* parent_search = nullptr,    // both given: twin expansions are evaluated once
+                               const QSort* qsort = nullptr);                                           // given: a round of >= min_groups expansions walks its items in the order launch_queue_sort left
+size_t bounds_queue_scratch_floats(int max_groups, int sorted_chunks = 0);
+hipError_t launch_chunk_centroids(const float4* src, int N, int chunk_pts, float4* cen, hipStream_t stream);
+hipError_t launch_queue_sort(const ParentRec* parents, const Rot9* rots, const int* d_groups, int max_groups, const QSort& qs, const DtDesc& dt, hipStream_t stream);
+int qsort_shift(int V);
+bool bounds_uses_lean(const DtDesc& dt);      // the launch picks the lean sibling path (and with it twin fusion and footprint-ordered items) for this grid
+size_t qsort_hist_bytes();
 // LDS-staged DT tiles for the deep expansions of a search (device.hip bounds_tile_kernel): nseg segments of n <= 64 expansions,
 // segs = nseg x {int off, int n, int rot}; stats (may be null): [0] sub-patches staged, [1] sub-patches whose box did not fit
 hipError_t launch_bounds_tile(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const ParentRec* parents, const void* segs, int nseg, int n,

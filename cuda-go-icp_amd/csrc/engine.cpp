@@ -510,6 +510,7 @@ void Engine::release()
 	if (stream_) hipStreamSynchronize(stream_);
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
 	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
+	hipFree(qsort_.keys); hipFree(qsort_.order); hipFree(qsort_.hist); hipFree(const_cast<float4*>(qsort_.cen)); qsort_ = QSort{};
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
 	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
 	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
@@ -1026,6 +1027,7 @@ void Engine::ensure_queues(size_t nsearch)
 	while (cap < nsearch) cap *= 2;
 	HIPCHK(hipStreamSynchronize(stream_));
 	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
+	hipFree(qsort_.keys); hipFree(qsort_.order); hipFree(qsort_.hist); hipFree(const_cast<float4*>(qsort_.cen)); qsort_ = QSort{};
 	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_);
 	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
 	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
@@ -1039,7 +1041,21 @@ void Engine::ensure_queues(size_t nsearch)
 	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qpsearch_[k], sizeof(int) * max_groups));
 	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
-	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups)));
+	// footprint-ordered items for the large rounds (lean grids, untrimmed, clouds of 4..128 chunks of 2 048 points)
+	constexpr int kSortChunkPts = 2048;          // measured on the full bunny (registration, ms): 1024 38.2 | 1536 34.8 | 2048 33.6 | 3072 34.4 | 4096 34.8; unsorted 36.8
+	const int sort_chunks = (int)((N_ + kSortChunkPts - 1) / kSortChunkPts);
+	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && sort_chunks >= 4 && sort_chunks <= 128) {
+		float4* cen = nullptr;
+		HIPCHK(hipMalloc(&cen, sizeof(float4) * sort_chunks));
+		HIPCHK(launch_chunk_centroids(d_src_, (int)N_, kSortChunkPts, cen, stream_));
+		qsort_.cen = cen;
+		HIPCHK(hipMalloc(&qsort_.keys, sizeof(unsigned) * max_groups * sort_chunks));
+		HIPCHK(hipMalloc(&qsort_.order, sizeof(unsigned) * max_groups * sort_chunks));
+		HIPCHK(hipMalloc(&qsort_.hist, qsort_hist_bytes()));
+		qsort_.chunk_pts = kSortChunkPts; qsort_.chunks = sort_chunks; qsort_.min_groups = 2048;                    // rounds from this many expansions: 512 35.0 | 1024 34.5 | 2048 33.6 | 4096 37.3 ms
+		qsort_.shift = qsort_shift(dt_.V);           // 16-voxel cells (32-voxel cells: 35.1 ms)
+	}
+	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups, qsort_.order ? qsort_.chunks : 0)));
 	if (tiles_usable()) {
 		// the second expansion list of a round (LDS-staged DT tiles): same capacity as the direct list
 		for (int k = 0; k < 2; k++) {
@@ -1094,6 +1110,10 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	// qualified (QCtl::tile_hint moved): shallow batches, i.e. every default registration, never pay for the extra launch
 	const bool tiles = qtile_.ub != nullptr;
 	const bool twins = p_.twin_fusion && d_qpsearch_[0] != nullptr;
+	// footprint-ordered items: the sort is queued only for rounds that can reach qsort_.min_groups expansions -- the first rounds of a
+	// batch by what a search can list in them (1, 8, 64 .. nodes), later ones by what the last read-back saw
+	long long round_cap = (long long)S;
+	bool sort_round = qsort_.order != nullptr;
 	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
 	tile_hint_seen_ = 0;
 	while (true) {
@@ -1103,8 +1123,11 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		for (int r = 0; r < chunk; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr,
 			                        twins ? d_qpsearch_[parity] : nullptr));
+			const bool sorted = sort_round && std::min<long long>(round_cap, max_groups) >= qsort_.min_groups;
+			if (sorted) HIPCHK(launch_queue_sort(d_qparents_[parity], d_rots_, &d_qctl_->n_groups[parity], max_groups, qsort_, bounds_dt(), stream_));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
-			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr));
+			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, sorted ? &qsort_ : nullptr));
+			if (round_cap < (1ll << 40)) round_cap *= 8;
 			if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
 			last = parity;
 			parity ^= 1;
@@ -1119,6 +1142,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
 		if ((h_qctl_->n_groups[last] == 0 && h_qctl_->n_tile_groups[last] == 0) || cancel_.load()) break;
 		if (tiles && p_.lds_tiles == 2) { qp.tile_on = h_qctl_->tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = h_qctl_->tile_hint; }
+		sort_round = qsort_.order != nullptr && h_qctl_->n_groups[last] >= qsort_.min_groups / 2;
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)

@@ -42,6 +42,7 @@ struct Params {
 	                              // DESIGN 4): ties are rare beyond level 2, no registration got faster -- default off
 	float ub_share = 0.f;         // opt-in, widened search: on top of a batch's parents by smallest lower bound, this fraction more are drawn by the smallest upper
 	                              // bound seen inside them (needs ub_tiebreak = 1 for the key).  Measured slower everywhere: default 0
+	int sort_items = 1;           // rounds of >= 2 048 expansions walk their (expansion, chunk) items in the order of where their gathers land (device.hip, launch_queue_sort)
 	int twin_fusion = 1;          // the same translation node listed by both searches of a rotation child in a round is gathered once (device.hip lean_points<.., 2>)
 	int lds_tiles = 2;            // LDS-staged DT tiles for inner searches whose selected nodes lie within a few voxels of each other (deep rounds): 0 off, 1 the
 	                              // tile evaluation is launched every round, 2 only while the previous rounds had searches that qualify (default)
@@ -252,6 +253,7 @@ private:
 	QSearch* d_qsearch_ = nullptr; QSearch* h_qsearch_ = nullptr;
 	QNode* d_qnodes_ = nullptr;
 	ParentRec* d_qparents_[2] = {nullptr, nullptr};
+	QSort qsort_{};                                     // footprint-ordered items of large rounds (device.hip); order == nullptr: off
 	int* d_qpsearch_[2] = {nullptr, nullptr};          // per listed expansion: the search that listed it (twin test of the bound evaluation)
 	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
 	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;

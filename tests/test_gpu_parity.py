@@ -1413,6 +1413,32 @@ def test_lds_tiles_on_the_search_path(pkg, bunny_model, bunny_data10):
     shallow.registration.close()
 
 
+def test_twin_fusion_and_footprint_ordered_items(pkg, bunny_model, bunny_data):
+    """Two launch-level mechanisms of the device-queue search, on the full bunny (BASELINE configs[1]; 460 inner searches in lock-step):
+    * Params::twin_fusion -- a translation node listed in the same round by both searches of a rotation child (GoICP::InnerBnB without and
+      with the rotation uncertainty, jly_goicp.cpp:494 / :532) is gathered from the distance transform once; each pass's sums see the
+      operations of a separate evaluation, so the registration is BIT-identical with the fusion on and off;
+    * Params::sort_items -- large rounds walk their (expansion, chunk) items in the order of the DT cell their gathers land in and cut the
+      cloud into 2 048-point chunks: no term of any bound changes, only the chunking of a cube's sum (last-bit differences), so the search
+      reaches the same optimum with node counts within 1 %."""
+    runs = {}
+    for name, kw in (("both", {}), ("no_twin", {"twin_fusion": 0}), ("no_sort", {"sort_items": 0}), ("neither", {"twin_fusion": 0, "sort_items": 0})):
+        eng = pkg.FastGoICP(bunny_model, bunny_data, 1e-3, **kw)
+        eng.run()
+        c = eng.counters
+        runs[name] = (float(eng.get_best_error()), eng.optR.copy(), eng.optT.copy(), int(c.cubes), int(c.rot_pops), int(c.trans_pops))
+        eng.registration.close()
+    for a, b in (("both", "no_twin"), ("no_sort", "neither")):              # twin fusion alone: same bits
+        assert runs[a][0] == runs[b][0] and np.array_equal(runs[a][1], runs[b][1]) and np.array_equal(runs[a][2], runs[b][2]), (a, b)
+        assert runs[a][3:] == runs[b][3:], (a, b, runs[a][3:], runs[b][3:])
+    sse, R, t, cubes, rot, trans = runs["both"]
+    sse0, R0, t0, cubes0, rot0, trans0 = runs["neither"]
+    assert abs(sse - sse0) <= 1e-5 * sse0 and rot_angle(R, R0) <= 1e-5 and np.abs(t - t0).max() <= 1e-5
+    assert abs(cubes - cubes0) <= 1e-2 * cubes0 and abs(rot - rot0) <= max(1, 1e-2 * rot0) and abs(trans - trans0) <= 1e-2 * trans0
+    g = golden("e2e_bunny_full")
+    assert sse <= 1.02 * g["sse"] and rot_angle(R, np.array(g["R"])) <= 2e-3
+
+
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     """Params::bounds_fp16 (opt-in, not the parity path): the BnB bounds read a half-precision copy of the bricked DT
     rounded toward zero.  Against the fp32 engine on the same cubes: every lower bound is <= the fp32 one (still a valid

@@ -355,6 +355,7 @@ __device__ __forceinline__ void bounds_item_store(const float (&ub)[kGroup], con
 // upper-bound pass).  The gathers of such a pair are identical; the lower-bound pass's item then evaluates both, the other leaves.
 struct TwinCtx { const QSearch* searches; const int* psearch; int* sh; };
 // a round of at least min_groups expansions walks its items in footprint order (launch_queue_sort below)
+constexpr int kSortBins = 1 << 15;                // Morton cells, 5 bits per axis
 __device__ __forceinline__ bool qsort_on(const QSort& qs, int ngroups) { return qs.order != nullptr && ngroups >= qs.min_groups; }
 
 // work item `work` of `total` = groups*chunks: one (cube group, point chunk) pair
@@ -897,6 +898,8 @@ __global__ __launch_bounds__(kBoundsThreads) void bounds_queue_kernel(
 	if (sorted) { groups = ngroups; chunks = qs.chunks; chunk_pts = qs.chunk_pts; }
 	else bounds_shape(ngroups * kGroup, N, &groups, &chunks, &chunk_pts);
 	if (blockIdx.x == 0 && threadIdx.x == 0) *d_chunks = chunks;          // > 1: the next round's digest adds the chunk partials up
+	if (sorted)                                                           // the order is built: leave the histogram zeroed for the next sorted round
+		for (int i = blockIdx.x * kBoundsThreads + threadIdx.x; i < kSortBins; i += gridDim.x * kBoundsThreads) qs.hist[i] = 0u;
 	const int total = groups * chunks;
 	const bool per_xcd = sorted || (total & 7) == 0;
 	const int slot = per_xcd ? (int)(blockIdx.x & 7) : 0, stride = per_xcd ? 8 : 1;
@@ -1148,7 +1151,6 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 // its own row); only the chunk count differs from the unsorted launch shape, i.e. the order in which a cube's per-chunk sums are added.
 // Measured (tools/round_probe.py, bunny, 230 rotations, both passes): children of level 2 1.22 -> 1.04 ms, of level 3 8.87 -> 6.81 ms.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSortBins = 1 << 15;                // 5 bits per axis
 __global__ __launch_bounds__(256) void chunk_centroid_kernel(const float4* __restrict__ src, int N, int chunk_pts, float4* __restrict__ cen)
 {
 	__shared__ float red[4][3];
@@ -1202,14 +1204,20 @@ __global__ void task_scatter_kernel(const int* __restrict__ d_groups, QSort qs)
 	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x)
 		qs.order[atomicAdd(&qs.hist[qs.keys[t]], 1u)] = (unsigned)t;          // order inside a bucket is arbitrary: no bound depends on it
 }
+// exclusive scan of the 32 768 counters by ONE workgroup: the whole histogram is staged in LDS (128 KB + padding against the 32-way bank
+// conflict of "thread t owns bins 32 t .. 32 t + 31"), coalesced both ways
 __global__ __launch_bounds__(1024) void task_scan_kernel(const int* __restrict__ d_groups, QSort qs)
 {
+	constexpr int per = kSortBins / 1024;            // 32 consecutive bins per thread
+	__shared__ unsigned lds[kSortBins + kSortBins / per];
 	__shared__ unsigned wtot[16];
 	if (!qsort_on(qs, *d_groups)) return;
-	constexpr int per = kSortBins / 1024;
-	const int b0 = threadIdx.x * per;
+	for (int i = threadIdx.x; i < kSortBins; i += 1024) lds[i + i / per] = qs.hist[i];
+	__syncthreads();
+	const int b0 = threadIdx.x * (per + 1);
 	unsigned local = 0;
-	for (int k = 0; k < per; k++) local += qs.hist[b0 + k];
+#pragma unroll
+	for (int k = 0; k < per; k++) local += lds[b0 + k];
 	unsigned incl = local;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
@@ -1218,7 +1226,10 @@ __global__ __launch_bounds__(1024) void task_scan_kernel(const int* __restrict__
 	unsigned before = 0;
 	for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wtot[w];
 	unsigned run = before + incl - local;
-	for (int k = 0; k < per; k++) { const unsigned c = qs.hist[b0 + k]; qs.hist[b0 + k] = run; run += c; }
+#pragma unroll
+	for (int k = 0; k < per; k++) { const unsigned c = lds[b0 + k]; lds[b0 + k] = run; run += c; }
+	__syncthreads();
+	for (int i = threadIdx.x; i < kSortBins; i += 1024) qs.hist[i] = lds[i + i / per];
 }
 int qsort_shift(int V) { int s = 0; while (((V - 1) >> s) >= 32) s++; return s; }   // 5 bits per axis: 16-voxel cells at V = 300 and 512
 size_t qsort_hist_bytes() { return sizeof(unsigned) * kSortBins; }
@@ -1226,8 +1237,7 @@ size_t qsort_hist_bytes() { return sizeof(unsigned) * kSortBins; }
 hipError_t launch_queue_sort(const ParentRec* parents, const Rot9* rots, const int* d_groups, int max_groups, const QSort& qs, const DtDesc& dt, hipStream_t stream)
 {
 	if (!qs.order || max_groups < qs.min_groups) return hipSuccess;
-	hipError_t e = hipMemsetAsync(qs.hist, 0, sizeof(unsigned) * kSortBins, stream);
-	if (e != hipSuccess) return e;
+	// qs.hist is all zero here: cleared at allocation, and again by the bound evaluation of every round that used it (bounds_queue_kernel)
 	const int blocks = (int)std::min<size_t>(((size_t)max_groups * qs.chunks + 255) / 256, 2048);
 	hipLaunchKernelGGL(task_key_kernel, dim3(blocks), dim3(256), 0, stream, parents, rots, d_groups, qs, dt);
 	hipLaunchKernelGGL(task_scan_kernel, dim3(1), dim3(1024), 0, stream, d_groups, qs);

@@ -1052,6 +1052,7 @@ void Engine::ensure_queues(size_t nsearch)
 		HIPCHK(hipMalloc(&qsort_.keys, sizeof(unsigned) * max_groups * sort_chunks));
 		HIPCHK(hipMalloc(&qsort_.order, sizeof(unsigned) * max_groups * sort_chunks));
 		HIPCHK(hipMalloc(&qsort_.hist, qsort_hist_bytes()));
+		HIPCHK(hipMemsetAsync(qsort_.hist, 0, qsort_hist_bytes(), stream_));     // kept zero between uses by the kernels themselves
 		qsort_.chunk_pts = kSortChunkPts; qsort_.chunks = sort_chunks; qsort_.min_groups = 2048;                    // rounds from this many expansions: 512 35.0 | 1024 34.5 | 2048 33.6 | 4096 37.3 ms
 		qsort_.shift = qsort_shift(dt_.V);           // 16-voxel cells (32-voxel cells: 35.1 ms)
 	}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-dispatch durations of the bound-evaluation kernels of ONE registration, in launch order, from a rocprofv3 kernel trace
-(rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/trace_e2e.py bunny).  usage: python3 tools/e2e_dispatches.py DIR"""
+(rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/trace_e2e.py bunny).  usage: python3 tools/e2e_dispatches.py DIR [kernel-name substring]"""
 import csv
 import glob
 import sys
@@ -30,3 +30,6 @@ for ts, short, d in out:
     line.append("%.0f" % d)
     prev = ts
 print("  " + " ".join(line))
+if len(sys.argv) > 2:                                       # any other kernel, by substring
+    print("%s dispatches in order (us):" % sys.argv[2])
+    print("  " + " ".join("%.0f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if sys.argv[2] in r["Kernel_Name"]))

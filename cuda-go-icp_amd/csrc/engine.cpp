@@ -1115,6 +1115,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	// batch by what a search can list in them (1, 8, 64 .. nodes), later ones by what the last read-back saw
 	long long round_cap = (long long)S;
 	bool sort_round = qsort_.order != nullptr;
+	int rounds_done = 0;
 	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
 	tile_hint_seen_ = 0;
 	while (true) {
@@ -1129,6 +1130,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
 			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, sorted ? &qsort_ : nullptr));
 			if (round_cap < (1ll << 40)) round_cap *= 8;
+			rounds_done++;
 			if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
 			last = parity;
 			parity ^= 1;
@@ -1143,7 +1145,9 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
 		if ((h_qctl_->n_groups[last] == 0 && h_qctl_->n_tile_groups[last] == 0) || cancel_.load()) break;
 		if (tiles && p_.lds_tiles == 2) { qp.tile_on = h_qctl_->tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = h_qctl_->tile_hint; }
-		sort_round = qsort_.order != nullptr && h_qctl_->n_groups[last] >= qsort_.min_groups / 2;
+		// (later rounds of a batch are narrow -- their expansions lie close together whatever the order -- and in long registrations the three
+		// extra launches per round are not free on the host side: mse 1e-4 bunny 295 vs 302 ms with the sort queued in every wide round)
+		sort_round = qsort_.order != nullptr && h_qctl_->n_groups[last] >= qsort_.min_groups && rounds_done < 7;
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)

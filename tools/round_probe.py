@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The early rounds of a rotation batch as a stand-alone batch: R rotations x ALL translation cubes of one level (as the 8 children of
-every cube of the level above), both passes.  What the bound evaluation costs on such a batch under a given launch shape
-(GOICP_SORT_CHUNK etc. are read by the library).  usage: python3 tools/round_probe.py [nrot=64] [levels=1,2,3] [iters=5]"""
+every cube of the level above), both passes.  What the bound evaluation costs on such a batch through the operator API (search-order items,
+bounds_shape's launch shape).  The footprint-ordered form of DESIGN 3.8 was first measured with this batch (an experimental hook in
+launch_bounds, since removed: 230 rotations, children of level 2 1.22 -> 1.04 ms, of level 3 8.87 -> 6.81 ms); it now lives in the
+device-queue search only (launch_queue_sort).  usage: python3 tools/round_probe.py [nrot=64] [levels=1,2,3] [iters=5]"""
 import ctypes as C
 import os
 import sys

@@ -67,21 +67,17 @@ __device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, floa
 
 }  // namespace
 
-// nodes of search s: q[s * kQueueCap ...]
-__global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
-                                                              const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
-                                                              const float* __restrict__ ubs, const float* __restrict__ lbs,
-                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile, int* __restrict__ parent_search)
+// One round of one search (the body of bnb_queue_kernel).  PER = queue slots held per thread: 8 covers the whole slab; 1 is the same code for
+// a search whose queue cannot exceed 1 024 nodes this round (count + 8 x last round's expansions) -- every default registration's searches, most
+// rounds: the per-slot loops (ballots, rank scans, key loads) then run once instead of eight times.  The kernel with 460 searches in lock-step is
+// bound by its instruction count (16 wavefronts per search, two searches per CU): 40-58 us per round before, measured below.
+template <int PER>
+__device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S, QNode* __restrict__ Q, const QParams& qp,
+                                            const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
+                                            const float* __restrict__ ubs, const float* __restrict__ lbs, const float* __restrict__ scratch,
+                                            QCtl* __restrict__ ctl, int parity, const QTile& tile, int* __restrict__ parent_search, int s)
 {
-	__shared__ QShared sh;
-	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	QSearch* __restrict__ S = searches + s;
-	QNode* __restrict__ Q = q + (size_t)s * kQueueCap;
-	if (s == 0 && tid < 8) {
-		if (tid == 0) { ctl->n_groups[parity ^ 1] = 0; ctl->n_tile_groups[parity ^ 1] = 0; ctl->n_tile_segs[parity ^ 1] = 0; }   // the next round's counters (their last readers have finished)
-		ctl->work[parity][tid] = 0;                                   // this round's work counters of the bound evaluation
-	}
-	if (S->done) return;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
 	float best = S->best;
 	int count = S->count;
@@ -161,23 +157,23 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			// SSEThresh of the incumbent since it was pushed fails the stop rule (jly_goicp.cpp:257) whenever it is popped --
 			// in a long upper-bound search the incumbent keeps falling and most of the queue is such dead weight.  Survivors
 			// keep their order.  (The reference's heap just grows; the slab cannot.)
-			QNode nd[kQPer];
-			bool keep[kQPer];
+			QNode nd[PER];
+			bool keep[PER];
 #pragma unroll
-			for (int j = 0; j < kQPer; j++) {
+			for (int j = 0; j < PER; j++) {
 				const int i = j * kQThreads + tid;
 				keep[j] = false;
 				if (i < count) { nd[j] = Q[i]; keep[j] = !(best - nd[j].lb < qp.thr); }
 			}
 #pragma unroll
-			for (int j = 0; j < kQPer; j++) {
+			for (int j = 0; j < PER; j++) {
 				const unsigned long long kb = __ballot(keep[j]);
 				if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(kb);
 			}
 			__syncthreads();                                              // every node is in registers; the counts are in LDS
 			{
 				unsigned wbefore = 0, tot = 0;
-				if (lane < kQPer)
+				if (lane < PER)
 					for (int w2 = 0; w2 < kQThreads / 64; w2++) {
 						const unsigned c = sh.cnt[lane][w2];
 						tot += c;
@@ -185,14 +181,14 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 					}
 				unsigned incl = tot;
 #pragma unroll
-				for (int o = 1; o < kQPer; o <<= 1) {
+				for (int o = 1; o < PER; o <<= 1) {
 					const unsigned v = __shfl_up(incl, o, 64);
 					if (lane >= o) incl += v;
 				}
 				const unsigned base = incl - tot + wbefore;               // lane j: survivors before (slot j, this wavefront)
-				if (tid == kQPer - 1) sh.bcast = (int)incl;               // wavefront 0: the number of survivors
+				if (tid == PER - 1) sh.bcast = (int)incl;               // wavefront 0: the number of survivors
 #pragma unroll
-				for (int j = 0; j < kQPer; j++) {
+				for (int j = 0; j < PER; j++) {
 					const unsigned long long kb = __ballot(keep[j]);
 					if (keep[j]) Q[(unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(kb & ((1ull << lane) - 1ull))] = nd[j];
 				}
@@ -225,10 +221,10 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	if (qp.stale_widen == 1) K = stale >= 3 ? min(4 * qp.K, kQueueMaxPop) : (stale >= 1 ? min(2 * qp.K, kQueueMaxPop) : qp.K);
 	else if (qp.stale_widen == 2) K = stale >= 1 ? min(4 * qp.K, kQueueMaxPop) : qp.K;
 	else if (qp.stale_widen == 3) K = stale >= 1 ? min(4 * qp.K, kQueueMaxPop) : min(2 * qp.K, kQueueMaxPop);
-	unsigned key[kQPer];
-	float lbv[kQPer];
+	unsigned key[PER];
+	float lbv[PER];
 #pragma unroll
-	for (int j = 0; j < kQPer; j++) {
+	for (int j = 0; j < PER; j++) {
 		const int i = j * kQThreads + tid;
 		if (i < n) {
 			const QNode nd = Q[i];
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	unsigned kmin = 0xffffffffu;
 	float lbmin = INFINITY;
 #pragma unroll
-	for (int j = 0; j < kQPer; j++) if (key[j] < kmin) { kmin = key[j]; lbmin = lbv[j]; }
+	for (int j = 0; j < PER; j++) if (key[j] < kmin) { kmin = key[j]; lbmin = lbv[j]; }
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
 		const unsigned ok = __shfl_xor(kmin, o, 64);
@@ -271,7 +267,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			__syncthreads();
 			const unsigned prefix = sh.sel_prefix;
 #pragma unroll
-			for (int j = 0; j < kQPer; j++) {
+			for (int j = 0; j < PER; j++) {
 				const bool live = j * kQThreads + tid < n && (pass == 0 || (key[j] >> (shift + width)) == prefix);
 				if (live) atomicAdd(&sh.hist[(key[j] >> shift) & (unsigned)(bins - 1)], 1u);
 			}
@@ -310,16 +306,16 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	}
 	// selected flags; the ties (key == T) are taken in queue order.  Per (j, wavefront) tie counts, then ranks.
 	unsigned tie_before[1] = {0};
-	bool sel[kQPer];
+	bool sel[PER];
 	if (n > K) {
 #pragma unroll
-		for (int j = 0; j < kQPer; j++) {
+		for (int j = 0; j < PER; j++) {
 			const unsigned long long tb = __ballot(key[j] == T);
 			if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(tb);
 		}
 		__syncthreads();
 		unsigned wbefore = 0, total = 0;
-		if (lane < kQPer)
+		if (lane < PER)
 			for (int w2 = 0; w2 < kQThreads / 64; w2++) {
 				const unsigned c = sh.cnt[lane][w2];
 				total += c;
@@ -327,13 +323,13 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			}
 		unsigned incl = total;
 #pragma unroll
-		for (int o = 1; o < kQPer; o <<= 1) {
+		for (int o = 1; o < PER; o <<= 1) {
 			const unsigned v = __shfl_up(incl, o, 64);
 			if (lane >= o) incl += v;
 		}
 		const unsigned base = incl - total + wbefore;                    // lane j: ties before (iteration j, this wavefront)
 #pragma unroll
-		for (int j = 0; j < kQPer; j++) {
+		for (int j = 0; j < PER; j++) {
 			const bool tie = key[j] == T;
 			const unsigned long long tb = __ballot(tie);
 			const unsigned rank = (unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(tb & ((1ull << lane) - 1ull));
@@ -342,23 +338,23 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		__syncthreads();
 	} else {
 #pragma unroll
-		for (int j = 0; j < kQPer; j++) sel[j] = j * kQThreads + tid < n;
+		for (int j = 0; j < PER; j++) sel[j] = j * kQThreads + tid < n;
 	}
 	(void)tie_before;
 	// the stop rule per node (:257): a selected node that can no longer close the gap stays queued
 #pragma unroll
-	for (int j = 0; j < kQPer; j++) sel[j] = sel[j] && !(best - lbv[j] < qp.thr);
+	for (int j = 0; j < PER; j++) sel[j] = sel[j] && !(best - lbv[j] < qp.thr);
 
 	// rank of every selected node in queue order -> slot in this round's expansion list
 #pragma unroll
-	for (int j = 0; j < kQPer; j++) {
+	for (int j = 0; j < PER; j++) {
 		const unsigned long long sb = __ballot(sel[j]);
 		if (lane == 0) sh.cnt[j][wave] = (unsigned short)__popcll(sb);
 	}
 	__syncthreads();
 	{
 		unsigned wbefore = 0, total = 0;
-		if (lane < kQPer)
+		if (lane < PER)
 			for (int w2 = 0; w2 < kQThreads / 64; w2++) {
 				const unsigned c = sh.cnt[lane][w2];
 				total += c;
@@ -366,14 +362,14 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 			}
 		unsigned incl = total;
 #pragma unroll
-		for (int o = 1; o < kQPer; o <<= 1) {
+		for (int o = 1; o < PER; o <<= 1) {
 			const unsigned v = __shfl_up(incl, o, 64);
 			if (lane >= o) incl += v;
 		}
 		const unsigned base = incl - total + wbefore;
-		if (tid == kQPer - 1) sh.n_sel = (int)incl;                       // wavefront 0, lane 31: total over all (j, wavefront)
+		if (tid == PER - 1) sh.n_sel = (int)incl;                       // wavefront 0, lane 31: total over all (j, wavefront)
 #pragma unroll
-		for (int j = 0; j < kQPer; j++) {
+		for (int j = 0; j < PER; j++) {
 			const unsigned long long sb = __ballot(sel[j]);
 			if (sel[j]) {
 				const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)base, j) + (unsigned)__popcll(sb & ((1ull << lane) - 1ull));
@@ -448,7 +444,7 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 	{
 		// which of the (at most n_sel) tail positions [m, n) are themselves selected: their owners say so
 #pragma unroll
-		for (int j = 0; j < kQPer; j++) {
+		for (int j = 0; j < PER; j++) {
 			const int i = j * kQThreads + tid;
 			if (i >= m && i < n) sh.tail_sel[i - m] = sel[j] ? 1 : 0;
 		}
@@ -468,6 +464,25 @@ __global__ __launch_bounds__(kQThreads) void bnb_queue_kernel(QSearch* __restric
 		if (filler) Q[sh.hole_pos[frank]] = moved;
 	}
 	if (tid == 0) { S->best = best; S->count = m; S->n_parents = n_sel; S->parent_off = off; S->tile = to_tile ? 1 : 0; S->deep = deep_now ? 1 : 0; S->stale = stale; }
+}
+
+// nodes of search s: q[s * kQueueCap ...]
+__global__ __launch_bounds__(kQThreads, 8) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
+                                                              const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
+                                                              const float* __restrict__ ubs, const float* __restrict__ lbs,
+                                                              const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile, int* __restrict__ parent_search)
+{
+	__shared__ QShared sh;
+	const int s = blockIdx.x, tid = threadIdx.x;
+	QSearch* __restrict__ S = searches + s;
+	QNode* __restrict__ Q = q + (size_t)s * kQueueCap;
+	if (s == 0 && tid < 8) {
+		if (tid == 0) { ctl->n_groups[parity ^ 1] = 0; ctl->n_tile_groups[parity ^ 1] = 0; ctl->n_tile_segs[parity ^ 1] = 0; }   // the next round's counters (their last readers have finished)
+		ctl->work[parity][tid] = 0;                                   // this round's work counters of the bound evaluation
+	}
+	if (S->done) return;
+	if (S->count + 8 * S->n_parents <= kQThreads) queue_round<1>(sh, S, Q, qp, prev_parents, parents, ubs, lbs, scratch, ctl, parity, tile, parent_search, s);
+	else queue_round<kQPer>(sh, S, Q, qp, prev_parents, parents, ubs, lbs, scratch, ctl, parity, tile, parent_search, s);
 }
 
 __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, int nsearch, QParams qp, QCtl* __restrict__ ctl)

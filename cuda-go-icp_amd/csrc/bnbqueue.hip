@@ -69,8 +69,10 @@ __device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, floa
 
 // One round of one search (the body of bnb_queue_kernel).  PER = queue slots held per thread: 8 covers the whole slab; 1 is the same code for
 // a search whose queue cannot exceed 1 024 nodes this round (count + 8 x last round's expansions) -- every default registration's searches, most
-// rounds: the per-slot loops (ballots, rank scans, key loads) then run once instead of eight times.  The kernel with 460 searches in lock-step is
-// bound by its instruction count (16 wavefronts per search, two searches per CU): 40-58 us per round before, measured below.
+// rounds: the per-slot loops (ballots, rank scans, key loads) then run once instead of eight times.  Measured on the full bunny (460 searches in
+// lock-step, rocprofv3 per dispatch): 40-58 -> 35-50 us per large round, 2.27 -> 1.75 ms per registration; with the kernel held to 64 VGPRs
+// (__launch_bounds__(1024, 8): four spilled registers on the rare purge path) two searches share a CU instead of one: bound-evaluation + queue
+// time of the registration 17.5 -> 17.1 ms.  What is left of a round is its chain of ~15 barriers and ~6 dependent memory round trips.
 template <int PER>
 __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S, QNode* __restrict__ Q, const QParams& qp,
                                             const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,

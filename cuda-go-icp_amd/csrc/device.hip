@@ -1147,7 +1147,7 @@ hipError_t launch_bounds_queue(const float4* src, int N, const DtDesc& dt, const
 // 4-byte lookups; 75-110 CU cycles per gather against 37 when the lines are found in L2).  So for large rounds the (expansion, chunk)
 // items are bucketed by WHERE their gathers land -- the Morton cell (16 voxels) of R * centroid(chunk) + centre(parent cube) -- with a
 // counting sort (key + histogram, scan, scatter), XCD x walks the x-th eighth of the sorted list, and the cloud is cut into smaller
-// chunks (2 048 points: a ~64-voxel patch) so that an item's footprint is compact.  The order changes no bound (an item's sums go to
+// chunks of 4 096 points (a ~90-voxel patch; the engine picks the size) so that an item's footprint stays compact.  The order changes no bound (an item's sums go to
 // its own row); only the chunk count differs from the unsorted launch shape, i.e. the order in which a cube's per-chunk sums are added.
 // Measured (tools/round_probe.py, bunny, 230 rotations, both passes): children of level 2 1.22 -> 1.04 ms, of level 3 8.87 -> 6.81 ms.
 // ------------------------------------------------------------------------------------------------

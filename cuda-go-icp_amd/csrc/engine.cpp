@@ -1041,10 +1041,13 @@ void Engine::ensure_queues(size_t nsearch)
 	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qpsearch_[k], sizeof(int) * max_groups));
 	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
 	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
-	// footprint-ordered items for the large rounds (lean grids, untrimmed, clouds of 4..128 chunks of 2 048 points)
-	constexpr int kSortChunkPts = 2048;          // measured on the full bunny (registration, ms): 1024 38.2 | 1536 34.8 | 2048 33.6 | 3072 34.4 | 4096 34.8; unsorted 36.8
+	// footprint-ordered items for the large rounds (lean grids, untrimmed, clouds of 4..16 chunks of 4 096 points).  Measured, registration in ms,
+	// chunk 2 048 | 3 072 | 4 096 | 6 144 | search order: bunny 34.4 | 33.1 | 33.8 | 34.1 | 36.8 (run-to-run +-0.6); bunny mse 1e-4 280 | 277 | 280 | 276 | 295;
+	// synthetic 40 k mse 3e-5 798 | 758 | 714 | 725 | 921; spanner 150 k mse 2e-5 223 | 212 | 206 | 201 | 195 -- above ~64 k points the unsorted
+	// launch's large chunks win, so the feature stops there
+	constexpr int kSortChunkPts = 4096;
 	const int sort_chunks = (int)((N_ + kSortChunkPts - 1) / kSortChunkPts);
-	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && sort_chunks >= 4 && sort_chunks <= 128) {
+	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && sort_chunks >= 4 && sort_chunks <= 16) {
 		float4* cen = nullptr;
 		HIPCHK(hipMalloc(&cen, sizeof(float4) * sort_chunks));
 		HIPCHK(launch_chunk_centroids(d_src_, (int)N_, kSortChunkPts, cen, stream_));

@@ -165,7 +165,7 @@ typedef struct goicp_params {
 	                          * round its 8 children are gathered from the distance transform ONCE and the two passes' sums are formed from the
 	                          * same fetched values (bit-identical to separate evaluations).  0: every listed node is evaluated on its own */
 	int32_t sort_items;      /* 1 (default): a round of >= 2 048 expansions (the first rounds of a rotation batch: hundreds of rotations x whole levels of
-	                          * the translation tree) walks its (expansion, 2 048-point chunk) work items in the order of the distance-transform cell
+	                          * the translation tree) walks its (expansion, 4 096-point chunk) work items in the order of the distance-transform cell
 	                          * their gathers land in, so that an XCD's L2 serves neighbouring items instead of streaming the grid from the Infinity
 	                          * Cache.  Changes no bound's terms, only the chunking of its sum.  0: search order */
 } goicp_params;

@@ -1419,7 +1419,7 @@ def test_twin_fusion_and_footprint_ordered_items(pkg, bunny_model, bunny_data):
       with the rotation uncertainty, jly_goicp.cpp:494 / :532) is gathered from the distance transform once; each pass's sums see the
       operations of a separate evaluation, so the registration is BIT-identical with the fusion on and off;
     * Params::sort_items -- large rounds walk their (expansion, chunk) items in the order of the DT cell their gathers land in and cut the
-      cloud into 2 048-point chunks: no term of any bound changes, only the chunking of a cube's sum (last-bit differences), so the search
+      cloud into 4 096-point chunks: no term of any bound changes, only the chunking of a cube's sum (last-bit differences), so the search
       reaches the same optimum with node counts within 1 %."""
     runs = {}
     for name, kw in (("both", {}), ("no_twin", {"twin_fusion": 0}), ("no_sort", {"sort_items": 0}), ("neither", {"twin_fusion": 0, "sort_items": 0})):

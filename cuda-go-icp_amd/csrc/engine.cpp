@@ -1563,6 +1563,7 @@ QParams Engine::queue_params() const
 	qp.tile_spread = tiles_usable() ? (float)((double)p_.tile_spread_vox / dt_.scale) : 0.f;
 	qp.tile_stats = p_.verbose ? 1 : 0; qp.tile_stats_scale = (float)dt_.scale;
 	qp.stale_widen = p_.adaptive_k ? p_.stale_widen : 0;
+	qp.stale_compact = p_.adaptive_k && p_.stale_widen ? p_.stale_compact : 0;
 
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;

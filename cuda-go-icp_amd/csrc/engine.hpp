@@ -50,6 +50,8 @@ struct Params {
 	int stale_widen = 1;          // adaptive_k: an inner search whose incumbent did not improve in its last round(s) is PROVING, not finding: every queued node whose lower
 	                              // bound is more than SSEThresh below the incumbent has to be expanded whatever the order, so a wider round wastes nothing -- its width
 	                              // doubles after one such round and again after three (lower-bound searches almost never improve; upper-bound searches until they settle)
+	int stale_compact = 2048;     // a proving inner search whose queue holds at least this many nodes selects by Morton order of the cubes' corners instead of by lower
+	                              // bound (spatially compact, depth-first-like: LDS-tile material, and the slab stops overflowing); 0: always by lower bound
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)

@@ -168,6 +168,11 @@ typedef struct goicp_params {
 	                          * the translation tree) walks its (expansion, 4 096-point chunk) work items in the order of the distance-transform cell
 	                          * their gathers land in, so that an XCD's L2 serves neighbouring items instead of streaming the grid from the Infinity
 	                          * Cache.  Changes no bound's terms, only the chunking of its sum.  0: search order */
+	int32_t stale_compact;   /* default 2048.  A proving inner search (stale_widen) whose queue holds at least this many nodes selects its next nodes by
+	                          * the Morton order of their corners instead of by lower bound: every queued node that passes the stop rule
+	                          * (jly_goicp.cpp:257) has to be expanded whatever the order, a run of Morton-neighbours is spatially compact (LDS-tile
+	                          * material) and is explored depth-first-like, so the queue slab stops overflowing into the host fall-back.  0: always
+	                          * by lower bound (the reference's order, jly_goicp.h:64-71) */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);

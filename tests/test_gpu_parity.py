@@ -1439,6 +1439,26 @@ def test_twin_fusion_and_footprint_ordered_items(pkg, bunny_model, bunny_data):
     assert sse <= 1.02 * g["sse"] and rot_angle(R, np.array(g["R"])) <= 2e-3
 
 
+def test_compact_selection_of_proving_searches(pkg, bunny_model, bunny_data10):
+    """Params::stale_compact: a proving inner search with a large queue takes its nodes in Morton order of their corners instead of by
+    lower bound.  Every queued node that passes the stop rule (jly_goicp.cpp:257) is expanded whatever the order, so a registration
+    that has to dig (threshold below the optimum's error) proves the same optimum either way; the counts differ by the few nodes an
+    incumbent that improves later lets through (measured +1..4 %)."""
+    runs = {}
+    for sc in (0, 2048, 256):
+        eng = pkg.FastGoICP(bunny_model, bunny_data10, 1e-4, stale_compact=sc)
+        eng.run()
+        c = eng.counters
+        runs[sc] = (float(eng.get_best_error()), eng.optR.copy(), eng.optT.copy(), int(c.cubes), int(c.rot_pops))
+        eng.registration.close()
+    sse0, R0, t0, cubes0, rot0 = runs[0]
+    for sc in (2048, 256):
+        sse, R, t, cubes, rot = runs[sc]
+        assert abs(sse - sse0) <= 1e-5 * sse0 and rot_angle(R, R0) <= 1e-5 and np.abs(t - t0).max() <= 1e-5
+        assert rot == rot0 and abs(cubes - cubes0) <= 0.10 * cubes0, (sc, cubes, cubes0)
+    assert runs[256][3] != cubes0                                  # the order really changed
+
+
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     """Params::bounds_fp16 (opt-in, not the parity path): the BnB bounds read a half-precision copy of the bricked DT
     rounded toward zero.  Against the fp32 engine on the same cubes: every lower bound is <= the fp32 one (still a valid

@@ -32,7 +32,7 @@ namespace {
 constexpr int kQThreads = 1024;
 constexpr int kQPer = kQueueCap / kQThreads;      // keys per thread held in registers (8)
 static_assert(kQueueCap % kQThreads == 0 && kQPer <= 64, "queue capacity / threads = keys per thread");
-static_assert(8 * kQueueMaxPop <= kQThreads && kQueueMaxPop <= 128, "one thread per child; the hole filling uses two wavefronts");
+static_assert(kQueueMaxPop <= kQThreads && kQueueMaxPop % 64 == 0, "one thread per selected node; the digest takes 1 024 children per pass");
 
 struct QShared {
 	unsigned hist[2048];
@@ -45,9 +45,9 @@ struct QShared {
 	int red_idx[kQThreads / 64];
 	unsigned push_tot[kQThreads / 64];
 	int n_sel, n_holes, parent_off, bcast;
-	int hole_cnt[2], fill_cnt[2];
-	float ext[2][6];                               // tile-list test: min / max corner of the selected nodes, per wavefront
-	float ext_w[2];
+	int hole_cnt[kQueueMaxPop / 64], fill_cnt[kQueueMaxPop / 64];
+	float ext[kQueueMaxPop / 64][6];               // tile-list test: min / max corner of the selected nodes, per wavefront
+	float ext_w[kQueueMaxPop / 64];
 	unsigned char tail_sel[kQueueMaxPop];          // removal: is tail position m + t one of the selected nodes?
 	float psum[2 * kQThreads];                     // digest: partial sums of the chunk partials, [child][part] for ub, then for lb
 };
@@ -89,11 +89,17 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 	// digest: the bounds of the children evaluated in the previous round (8 per expansion, <= 256 children)
 	// ------------------------------------------------------------------------------------------------------------
 	if (n_prev > 0) {
-		const int C = 8 * n_prev, off = S->parent_off;
-		const bool mine = tid < C;
+		const int Ctot = 8 * n_prev, off = S->parent_off;
 		// the previous round listed this search's expansions in the tile list: its bounds, partial sums and records live there
 		if (S->tile) { prev_parents = tile.parents[parity ^ 1]; ubs = tile.ub; lbs = tile.lb; scratch = tile.scratch; }
 		const int chunks = S->tile ? ctl->tile_chunks : ctl->chunks;
+		bool improved_any = false;
+		// one thread per child, 1 024 children per pass (a lone search may have expanded up to 512 nodes: four passes; a pass prunes with the
+		// incumbent of the children seen so far -- later passes only tighten it, and a node kept too long fails the stop rule when it is selected)
+#pragma unroll 1
+		for (int cb = 0; cb < Ctot; cb += kQThreads) {
+		const int C = min(kQThreads, Ctot - cb);
+		const bool mine = tid < C;
 		// The evaluation split the cloud into `chunks` chunks: its per-chunk sums are added here (this replaces a finalize launch
 		// per round).  Small rounds have few children and many chunks (up to 118), so the sum is spread over the workgroup: P
 		// threads per child add every P-th chunk partial, the child's own thread adds the P results in order.  Fixed order
@@ -102,7 +108,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 		if (chunks > 1) {
 			if (tid < C * P) {
 				const int c = tid / P, p = tid - c * P;
-				const float* sp = scratch + ((size_t)(off + (c >> 3)) * chunks) * (2 * kGroup) + (c & 7);
+				const float* sp = scratch + ((size_t)(off + ((cb + c) >> 3)) * chunks) * (2 * kGroup) + (c & 7);
 				float a = 0.f, b = 0.f;
 				for (int j = p; j < chunks; j += P) { a += sp[(size_t)j * 2 * kGroup]; b += sp[(size_t)j * 2 * kGroup + kGroup]; }
 				sh.psum[tid] = a; sh.psum[kQThreads + tid] = b;
@@ -112,7 +118,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 		float cx = 0.f, cy = 0.f, cz = 0.f, cw = 0.f, ub = INFINITY, lb = INFINITY;
 		bool valid = false;
 		if (mine) {
-			const ParentRec pr = prev_parents[off + (tid >> 3)];
+			const ParentRec pr = prev_parents[off + ((cb + tid) >> 3)];
 			const int c = tid & 7;
 			cw = pr.w / 2;                                            // jly_goicp.cpp:262-270
 			cx = pr.x + (float)(c & 1) * cw; cy = pr.y + (float)((c >> 1) & 1) * cw; cz = pr.z + (float)((c >> 2) & 1) * cw;
@@ -121,7 +127,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 				for (int p = 0; p < P; p++) { a += sh.psum[tid * P + p]; b += sh.psum[kQThreads + tid * P + p]; }
 				ub = a; lb = b;
 			} else {
-				ub = ubs[(size_t)8 * off + tid]; lb = lbs[(size_t)8 * off + tid];
+				ub = ubs[(size_t)8 * off + cb + tid]; lb = lbs[(size_t)8 * off + cb + tid];
 			}
 			valid = !qp.boxed || in_box(qp, cx, cy, cz, cw);         // outside the configured translation range: not a candidate
 		}
@@ -142,7 +148,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			if (sh.red_ub[w2] < mub || (sh.red_ub[w2] == mub && sh.red_idx[w2] < midx)) { mub = sh.red_ub[w2]; midx = sh.red_idx[w2]; }
 		const bool improved = mub < best;
 		if (tid == 0 && mub < S->min_ub) S->min_ub = mub;
-		stale = improved ? 0 : stale + 1;
+		improved_any = improved_any || improved;
 		if (improved) best = mub;
 		if (improved && tid == midx) { S->bx = cx; S->by = cy; S->bz = cz; S->bw = cw; S->improved = 1; }
 		// push the children that can still improve on the incumbent (:327-335), unless the depth limit says leaf
@@ -208,8 +214,10 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			Q[pos] = QNode{cx, cy, cz, cw, ub, lb};
 		}
 		count += (int)total;
-		if (tid == 0) { S->pops += n_prev; S->cubes += C; }
-		__syncthreads();                                                 // the pushed nodes are read back below
+		__syncthreads();                                                 // the pushed nodes are read back below; the LDS scratch is reused by the next pass
+		}
+		stale = improved_any ? 0 : stale + 1;
+		if (tid == 0) { S->pops += n_prev; S->cubes += Ctot; }
 	}
 
 	// ------------------------------------------------------------------------------------------------------------
@@ -228,6 +236,10 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 	// Morton-neighbours is (a) spatially compact -- LDS-tile material -- and (b) explored depth-first-like, so its children are pruned or finished
 	// before the queue has to hold another level of the whole frontier: the slab stops overflowing.  Measured, prove-the-optimum bunny: mse 3e-5
 	// 8.47 -> 6.79 s, five host fall-backs -> none; mse 2e-5 26.95 -> 22.3 s; +1.3 % cube bounds.
+	K = min(K, qp.kmax);                               // the searches still running x kmax fit the round's lists
+	if (K > kQueueRoundPop) K = max(kQueueRoundPop, min(K, (qp.cap - n) / 8));              // ... and the children of this round's expansions fit the slab (a big step into a nearly full
+	                                                   // queue would overflow it: the batch would go back to the host); steps of <= 128 are
+	                                                   // left alone -- throttling them by the room only adds rounds (measured)
 	const bool compact = qp.stale_compact > 0 && stale >= 1 && n >= qp.stale_compact;
 	unsigned key[PER];
 	float lbv[PER];
@@ -410,7 +422,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 	if (qp.tile_spread > 0.f) {
 		float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0.f;
 		if (tid < n_sel) { lo3[0] = hi3[0] = mine_nd.x; lo3[1] = hi3[1] = mine_nd.y; lo3[2] = hi3[2] = mine_nd.z; wmax = mine_nd.w; }
-		if (wave < 2) {
+		if (wave < kQueueMaxPop / 64) {
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -424,11 +436,17 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			}
 		}
 		__syncthreads();
-		float spread = 0.f;
+		float spread = 0.f, wmx = 0.f;
 #pragma unroll
-		for (int k = 0; k < 3; k++)
-			spread = fmaxf(spread, fmaxf(sh.ext[0][3 + k], sh.ext[1][3 + k]) - fminf(sh.ext[0][k], sh.ext[1][k]));
-		spread += fmaxf(sh.ext_w[0], sh.ext_w[1]);                      // the children's centres reach w/4 .. 3w/4 beyond the corners
+		for (int k = 0; k < 3; k++) {
+			float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+			for (int w2 = 0; w2 < kQueueMaxPop / 64; w2++) { lo = fminf(lo, sh.ext[w2][k]); hi = fmaxf(hi, sh.ext[w2][3 + k]); }
+			spread = fmaxf(spread, hi - lo);
+		}
+#pragma unroll
+		for (int w2 = 0; w2 < kQueueMaxPop / 64; w2++) wmx = fmaxf(wmx, sh.ext_w[w2]);
+		spread += wmx;                                                  // the children's centres reach w/4 .. 3w/4 beyond the corners
 		to_tile = spread <= qp.tile_spread;
 		deep_now = to_tile;
 		if (qp.tile_stats && tid == 0) {
@@ -447,9 +465,15 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			for (int k = 0; k < nseg; k++) tile.segs[parity][seg0 + k] = TileSeg{sh.parent_off + 64 * k, min(64, n_sel - 64 * k), S->rot};
 		} else
 			sh.parent_off = atomicAdd(&ctl->n_groups[parity], n_sel);
+		atomicAdd(&ctl->n_active[parity], 1);
 	}
 	__syncthreads();
 	const int off = sh.parent_off;
+	if (off + n_sel > qp.list_cap) {
+		// cannot happen while the host's kmax is what it should be; if it ever does, nothing is written past the lists: the batch goes to the host queues
+		if (tid == 0) { atomicExch(&ctl->overflow, 1); S->done = 1; S->n_parents = 0; }
+		return;
+	}
 	const float coeff = S->coeff;
 	const int rot = S->rot;
 	if (tid < n_sel) (to_tile ? tile.parents[parity] : parents)[off + tid] = ParentRec{mine_nd.x, mine_nd.y, mine_nd.z, mine_nd.w, coeff, rot};
@@ -470,10 +494,10 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 		const int tailpos = m + tid;
 		const bool filler = tid < n_sel && tailpos < n && !sh.tail_sel[tid < kQueueMaxPop ? tid : 0];
 		const unsigned long long hb = __ballot(is_hole), fb = __ballot(filler);
-		if (wave < 2 && lane == 0) { sh.hole_cnt[wave] = (int)__popcll(hb); sh.fill_cnt[wave] = (int)__popcll(fb); }
+		if (wave < kQueueMaxPop / 64 && lane == 0) { sh.hole_cnt[wave] = (int)__popcll(hb); sh.fill_cnt[wave] = (int)__popcll(fb); }
 		__syncthreads();
-		const int hrank = (wave == 1 ? sh.hole_cnt[0] : 0) + (int)__popcll(hb & ((1ull << lane) - 1ull));
-		const int frank = (wave == 1 ? sh.fill_cnt[0] : 0) + (int)__popcll(fb & ((1ull << lane) - 1ull));
+		int hrank = (int)__popcll(hb & ((1ull << lane) - 1ull)), frank = (int)__popcll(fb & ((1ull << lane) - 1ull));
+		for (int w2 = 0; w2 < min(wave, kQueueMaxPop / 64); w2++) { hrank += sh.hole_cnt[w2]; frank += sh.fill_cnt[w2]; }
 		if (is_hole) sh.hole_pos[hrank] = sh.sel_pos[tid];
 		QNode moved{};
 		if (filler) moved = Q[tailpos];
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(kQThreads, 8) void bnb_queue_kernel(QSearch* __rest
 	QSearch* __restrict__ S = searches + s;
 	QNode* __restrict__ Q = q + (size_t)s * kQueueCap;
 	if (s == 0 && tid < 8) {
-		if (tid == 0) { ctl->n_groups[parity ^ 1] = 0; ctl->n_tile_groups[parity ^ 1] = 0; ctl->n_tile_segs[parity ^ 1] = 0; }   // the next round's counters (their last readers have finished)
+		if (tid == 0) { ctl->n_groups[parity ^ 1] = 0; ctl->n_tile_groups[parity ^ 1] = 0; ctl->n_tile_segs[parity ^ 1] = 0; ctl->n_active[parity ^ 1] = 0; }   // the next round's counters (their last readers have finished)
 		ctl->work[parity][tid] = 0;                                   // this round's work counters of the bound evaluation
 	}
 	if (S->done) return;
@@ -506,7 +530,7 @@ __global__ void bnb_init_kernel(QSearch* __restrict__ searches, QNode* __restric
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s == 0) {
-		ctl->n_groups[0] = 0; ctl->n_groups[1] = 0; ctl->overflow = 0;
+		ctl->n_groups[0] = 0; ctl->n_groups[1] = 0; ctl->overflow = 0; ctl->n_active[0] = ctl->n_active[1] = 0;
 		for (int k = 0; k < 8; k++) { ctl->work[0][k] = 0; ctl->work[1][k] = 0; }
 		ctl->n_tile_groups[0] = ctl->n_tile_groups[1] = 0; ctl->n_tile_segs[0] = ctl->n_tile_segs[1] = 0; ctl->tile_chunks = 1; ctl->tile_hint = 0; ctl->tile_total = 0;
 		for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) ctl->sel_hist[a][b] = 0;

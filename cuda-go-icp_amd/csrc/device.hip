@@ -424,9 +424,9 @@ __device__ __forceinline__ void bounds_work(
 					if (tn > 0 && tw.searches[ts_].tile == 0) {
 						if (threadIdx.x == 0) *tw.sh = -1;
 						__syncthreads();
-						if ((int)threadIdx.x < tn) {
-							const ParentRec o = parents[toff + threadIdx.x], me = parents[group];
-							if (o.x == me.x && o.y == me.y && o.z == me.z && o.w == me.w && o.rot == me.rot && (o.coeff == 0.f) != (me.coeff == 0.f)) *tw.sh = toff + (int)threadIdx.x;
+						for (int j = threadIdx.x; j < tn; j += kBoundsThreads) {       // tn <= kQueueMaxPop
+							const ParentRec o = parents[toff + j], me = parents[group];
+							if (o.x == me.x && o.y == me.y && o.z == me.z && o.w == me.w && o.rot == me.rot && (o.coeff == 0.f) != (me.coeff == 0.f)) *tw.sh = toff + j;
 						}
 						__syncthreads();
 						twin = *tw.sh;

@@ -91,7 +91,9 @@ hipError_t launch_bounds_trim(const float4* src, int N, const DtDesc& dt, const 
 
 // ---- device-resident inner BnB (bnbqueue.hip): one queue per inner search, rounds without the host --------------
 constexpr int kQueueCap = 8192;     // nodes per search queue (a queue that would overflow sends the batch back to the host driver)
-constexpr int kQueueMaxPop = 128;   // most expansions per search and round (the driver uses 32 while many searches run and raises it for the stragglers)
+constexpr int kQueueMaxPop = 512;   // most expansions per search and round: what a LONE search may list (a round costs ~150 us of launches and barriers whatever it
+                                    // lists, so the last searches of a batch take big steps)
+constexpr int kQueueRoundPop = 128;  // ... and what the round's lists are sized for per search slot (QParams::kmax keeps the total inside: many searches, small steps)
 struct QNode { float x, y, z, w, ub, lb; };                    // corner + width (TRANSNODE, jly_goicp.h:59-72)
 struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:227-340)
 	float best;                     // optErrorT (in: the incumbent; out: the search's value)
@@ -124,6 +126,7 @@ struct QCtl {
 	int32_t tile_chunks;            // point chunks per segment of the last tile evaluation (its sums are chunk partials when > 1)
 	int32_t tile_hint;              // running count of (search, round) pairs that qualified for the tile list, whether it was on or not
 	int32_t tile_total;             // running count of expansions listed in the tile list
+	int32_t n_active[2];            // searches that listed expansions, per round parity (exact: the host sizes the next rounds' steps by it)
 	int32_t sel_hist[4][4];         // diagnostics (verbose): expansions selected, by [selection size < 16, < 32, < 64, >= 64][spread <= 5, <= 10, <= 20, > 20 voxels]
 };
 struct QTile {                      // buffers of the tile list (all null / zero: tiles off)
@@ -134,6 +137,8 @@ struct QTile {                      // buffers of the tile list (all null / zero
 struct QParams {
 	float thr;                      // SSEThresh
 	int32_t K;                      // expansions per search and round (<= kQueueMaxPop)
+	int32_t kmax;                   // cap on K after the kernel's own widening: searches still running x kmax fits the round's lists
+	int32_t list_cap;               // expansions the round's lists hold (a round that would exceed it flags overflow: host fallback)
 	float root_x, root_y, root_z, root_w;
 	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
 	int32_t cap;                    // nodes a queue may hold (<= kQueueCap; smaller values only to exercise the overflow path)

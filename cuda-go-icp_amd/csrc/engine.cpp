@@ -1033,7 +1033,8 @@ void Engine::ensure_queues(size_t nsearch)
 	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
 	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr; d_qpsearch_[0] = d_qpsearch_[1] = nullptr;
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
-	const size_t max_groups = cap * kQueueMaxPop;
+	const size_t max_groups = cap * kQueueRoundPop;          // what the round's lists hold; QParams::kmax keeps (searches running) x (their steps) inside
+	q_list_cap_ = (int)max_groups;
 	HIPCHK(hipMalloc(&d_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipHostMalloc(&h_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipMalloc(&d_qnodes_, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
@@ -1084,7 +1085,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 {
 	TraceRange tr("goicp:inner_bnb_rounds");
 	const size_t S = searches.size(), nrot = rots.size();
-	const int K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
+	const int K = std::min(std::max(1, p_.trans_batch), kQueueRoundPop);
 	ensure_queues(S);
 	ensure_batch(1, nrot);
 	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
@@ -1108,6 +1109,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * S, hipMemcpyHostToDevice, stream_));
 	QParams qp = queue_params();
 	qp.K = K;
+	qp.kmax = std::min(kQueueMaxPop, q_list_cap_ / (int)std::max<size_t>(S, 1));   // >= kQueueRoundPop: S <= the slots the lists were sized for
 	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
 	int parity = 0, chunk = 3;
 	// the tile list: always on (lds_tiles 1), or -- the default -- only for the rounds that follow a read-back in which searches
@@ -1124,7 +1126,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	while (true) {
 		const double t0 = now_ms();
 		int last = 0;
-		const int max_groups = (int)(S * (size_t)qp.K);
+		const int max_groups = (int)std::min<size_t>(S * (size_t)std::min(qp.kmax, 4 * qp.K), (size_t)q_list_cap_);   // most the round can list (the kernel widens a stale search's step up to x4)
 		for (int r = 0; r < chunk; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr,
 			                        twins ? d_qpsearch_[parity] : nullptr));
@@ -1155,9 +1157,12 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)
 		chunk = 4;
+		// exact: the searches that listed expansions in the last round (a search only ever finishes, so it bounds the rounds to come)
+		const int active = std::max(1, h_qctl_->n_active[last]);
+		qp.kmax = std::min(kQueueMaxPop, q_list_cap_ / active);
 		if (p_.adaptive_k && K >= 32) {
-			const int active_est = (h_qctl_->n_groups[last] + h_qctl_->n_tile_groups[last] + qp.K - 1) / qp.K;       // searches that filled their quota
-			qp.K = active_est <= 16 ? kQueueMaxPop : (active_est <= 64 ? std::min(kQueueMaxPop, 2 * K) : K);
+			// <= 16 running: up to 512 expansions each (swept 1 / 2 / 4 / 8 / 16 searches: the same within the run-to-run spread)
+			qp.K = active <= 16 ? kQueueMaxPop : (active <= 64 ? std::min(kQueueRoundPop, 2 * K) : K);
 		}
 	}
 	cnt_.tile_expansions += h_qctl_->tile_total;
@@ -1565,7 +1570,8 @@ QParams Engine::queue_params() const
 	qp.stale_widen = p_.adaptive_k ? p_.stale_widen : 0;
 	qp.stale_compact = p_.adaptive_k && p_.stale_widen ? p_.stale_compact : 0;
 
-	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueMaxPop);
+	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueRoundPop);
+	qp.kmax = kQueueRoundPop; qp.list_cap = q_list_cap_;     // any number of searches fits; run_inner_device raises kmax for the last few
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
 	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
@@ -1654,7 +1660,7 @@ int Engine::flow_step(int max_rot_pops)
 		// ---- a chunk of rounds over every slot in use ----
 		const double t0 = now_ms();
 		QParams qr = qp;
-		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueMaxPop : (flow_active_ <= 64 ? std::min(kQueueMaxPop, 2 * qp.K) : qp.K);
+		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueRoundPop : (flow_active_ <= 64 ? std::min(kQueueRoundPop, 2 * qp.K) : qp.K);
 		const int max_groups = q_hi_ * qr.K;
 		for (int r = 0; r < 3; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));

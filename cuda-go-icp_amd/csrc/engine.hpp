@@ -256,6 +256,7 @@ private:
 	QNode* d_qnodes_ = nullptr;
 	ParentRec* d_qparents_[2] = {nullptr, nullptr};
 	QSort qsort_{};                                     // footprint-ordered items of large rounds (device.hip); order == nullptr: off
+	int q_list_cap_ = 0;                                // expansions the round's lists (parents, bounds, partial sums) hold
 	int* d_qpsearch_[2] = {nullptr, nullptr};          // per listed expansion: the search that listed it (twin test of the bound evaluation)
 	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
 	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;

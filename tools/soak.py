@@ -56,5 +56,5 @@ for r in range(rounds):
         base = fm                                     # after the SECOND round: the runtime keeps a little of what the first round's engines freed
     if (r % 10 == 9 or r == rounds - 1) and base is not None:
         print("round %d: %.1f s, free device memory %+d KiB vs after the second round" % (r + 1, time.time() - t0, (fm - base) // 1024), flush=True)
-assert abs(free_mem() - base) <= (128 << 20), "device memory drifted"      # the level toggles by one cached 90 MiB block of the runtime (seen at 0 and -90 MiB, never growing)
+assert abs(free_mem() - base) <= (256 << 20), "device memory drifted"      # the level toggles by one or two cached ~93 MiB blocks of the runtime (seen at 0, -90 and -186 MiB, never growing: 100 rounds end at 0)
 print("soak ok: %d rounds x %d cases, bit-identical results, no memory drift" % (rounds, len(cases)))

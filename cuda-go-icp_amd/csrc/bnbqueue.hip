@@ -480,7 +480,7 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 	if (parent_search && !to_tile && tid < n_sel) parent_search[off + tid] = s;
 	__syncthreads();
 	// remove the selected nodes: the holes among the first m = n - n_sel positions are filled, in order, with the
-	// unselected nodes of the tail [m, n)  (at most n_sel <= 128 of each: the first two wavefronts do it)
+	// unselected nodes of the tail [m, n)  (at most n_sel <= kQueueMaxPop of each: the first eight wavefronts do it)
 	const int m = n - n_sel;
 	{
 		// which of the (at most n_sel) tail positions [m, n) are themselves selected: their owners say so

@@ -146,7 +146,7 @@ struct QParams {
 	int32_t tile_on;                // 1: searches that qualify are listed in the tile list this round (its evaluation is launched)
 	int32_t tile_min;               // fewest expansions for the tile list (a lane group of the tile kernel = one expansion)
 	float tile_spread;              // largest extent, per axis, of the selected nodes' translations (world units) for the tile list
-	int32_t stale_widen;            // 1: a search whose incumbent did not improve in its last round expands up to 2 K nodes, after three such rounds 4 K (<= 128)
+	int32_t stale_widen;            // 1: a search whose incumbent did not improve in its last round expands up to 2 K nodes, after three such rounds 4 K (<= kQueueMaxPop and QParams::kmax)
 	int32_t stale_compact;          // > 0: such a search takes its nodes in Morton order (compact, depth-first-like) once its queue holds this many (bnbqueue.hip)
 	int32_t tile_stats;             // 1: fill QCtl::sel_hist (verbose runs)
 	float tile_stats_scale;         // voxels per world unit

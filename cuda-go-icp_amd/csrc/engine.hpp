@@ -32,7 +32,7 @@ struct Params {
 	int bounds_fp16 = 0;          // 1: BnB cube bounds read a half-precision copy of the bricked DT (rounded toward zero: lower bounds stay valid, upper bounds low by <= 2^-10 relative); ICP, the DT re-score and trimmed bounds keep the fp32 grid.  Not bit-parity: opt-in
 	int icp_nn_cache = 0;         // 1: an ICP pass skips (exactly) the tree walk of every query whose cached neighbour is provably still the nearest (measured slower on real trajectories, DESIGN 3.6: opt-in); 0: every query walks every pass; bit-identical states either way
 	int flow = 0;                 // opt-in; L > 0: continuous flow over the device queues -- rotation children are harvested one by one and the next batch of parents is admitted when at most this many inner searches still run; 0: lock-step batches
-	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 128 nodes per round instead of trans_batch
+	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 512 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
 	int device_queues = 1;        // 1: inner-BnB queues live on the device, a round is two launches and no host work (bnbqueue.hip); 0: host queues (always used when trans_batch == 1 = the reference visit order)
 	int icp_point_seed = 1;       // 1: the ICP neighbour search starts every walk from a real candidate read from a per-voxel nearest-target-point table

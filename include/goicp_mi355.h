@@ -130,7 +130,7 @@ typedef struct goicp_params {
 	                          * both its inner searches have stopped, and the next rotation parents are admitted when at most L searches
 	                          * still run.  Same bounds and prune rules, same optimum; more speculative work -- faster or slower depending
 	                          * on which candidate happens to be refined first */
-	int32_t adaptive_k;      /* 1 (default): when few inner searches are still running (the stragglers of a batch) each may expand up to 128
+	int32_t adaptive_k;      /* 1 (default): when few inner searches are still running (the stragglers of a batch) each may expand up to 512
 	                          * nodes per round instead of trans_batch: fewer latency-bound rounds; 0: always trans_batch */
 	int32_t queue_cap;       /* test hook: nodes a device-resident queue may hold before its batch is re-run through the host queues
 	                          * (0 = the full 8 192-node slab) */

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- BnB cube bounds/sec (+ inner-ICP iterations/sec) of the MI355X Go-ICP engine.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run,
-one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N > 1 runs one rank per GPU over RCCL, started either way:
+  * by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or
+  * plainly, `python3 bench.py --gpus N ...` with no WORLD_SIZE in the environment: this process then starts the N ranks itself as
+    FRESH child processes (it never touches a GPU, never re-executes itself), forwards rank 0's JSON line to its stdout and
+    exits non-zero if any rank did.
+Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1], "bunny_goicp.toml Go-ICP on 1xMI355X, DT grid 300^3,
 subsample=1.0"): the Stanford-bunny clouds the reference's config names (M = 35 947 target,
@@ -42,11 +46,24 @@ def _profile(suffix):
     """Newest committed PMC summary profiles/rNN_<suffix> (the counters cannot be read from inside this process; they are
     collected with `rocprofv3 --pmc` on this command, tools/pmc_collect.sh, and committed)."""
     d = os.path.join(ROOT, "profiles")
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         p = os.path.join(d, "%s_%s" % (rnd, suffix))
         if os.path.exists(p):
             return p
     return None
+
+
+def _profile_traffic(path, key, lib_hash):
+    """(traffic bytes or None, provenance dict) of a committed PMC summary: the counters are only quoted when they were collected on the
+    kernels this library was built from (the summary's kernel_source_hash, stamped by tools/pmc_to_profile.py, equals the library's)."""
+    with open(path) as f:
+        j = json.load(f)
+    prov = {"traffic_profile": "profiles/" + os.path.basename(path), "traffic_profile_head": j.get("git_head", "unstamped (collected before round 4)"),
+            "traffic_profile_kernel_hash": j.get("kernel_source_hash"), "library_kernel_hash": lib_hash}
+    if j.get("kernel_source_hash") != lib_hash:
+        prov["traffic_null_because"] = "the committed counter profile was collected on other kernel sources than this library's: re-collect (tools/profile_round.sh)"
+        return None, prov, j
+    return j[key], prov, j
 
 
 def make_batch(pkg, reg, n_expansions, n_rot, seed):
@@ -182,16 +199,67 @@ def s2_leg(pkg, B, lib, args, dev, torch):
            "algorithmic_bytes_per_launch_survey": (Bc - n_lb) * 16.0 * N + n_lb * 20.0 * N, "algorithmic_bytes_per_launch_as_built": Bc * 6.0 * N}
     pmc = _profile("pmc_bounds_s2.json")
     if pmc and Bc == 65536:
-        with open(pmc) as f:
-            j = json.load(f)
-        tr = j["hbm_bytes_per_launch_corrected"]
-        res["roofline"] = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": round(tr / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(tr / launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
+        tr, prov, _ = _profile_traffic(pmc, "hbm_bytes_per_launch_corrected", lib.goicp_kernel_source_hash().decode())
+        alg = res["algorithmic_bytes_per_launch_survey"]
+        res["roofline"] = {"bound": "hbm", "kernel": "goicp::bounds_kernel", "achieved": None if tr is None else round(tr / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": None if tr is None else round(tr / launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
                            "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this batch, separate passes, FETCH_SIZE x2 on gfx950; fabric side of L2)" % os.path.basename(pmc),
                            "launch_ms": round(ms.value, 3),
+                           "frac_survey_model": round(alg / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_survey_model_is": "SURVEY 8(d)'s 16 N / 20 N bytes per cube bound over the launch time over 8 TB/s: above 1 -- void as a fraction, the model prices no sibling reuse (a point is loaded once per 8 cubes)",
                            "as_built_frac": round(Bc * 6.0 * N / launch_s / 1e9 / HBM_PEAK_GBS, 4)}
+        res["roofline"].update(prov)
     reg.close()
     return res
+
+
+def spawn_ranks(n, backend):
+    """`python3 bench.py --gpus N` started plainly: run the N ranks as fresh child processes of THIS one (which has not touched and
+    never touches the GPU -- no torch.cuda call, no HIP call), one per GPU, rendezvous on 127.0.0.1.  Rank 0's stdout (the ONE
+    JSON line) is forwarded to ours as it comes, the other ranks' stdout goes to stderr.  Exit code: 0 only if every rank's was 0;
+    when a rank fails the others get 30 s to notice (their collectives have deadlines) before they are ended -- by PID."""
+    import socket
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def pump(r, pipe):
+        for line in pipe:
+            # ONE JSON line on stdout: rank 0's; anything else a rank writes there (gloo prints its connection banner to stdout) goes to stderr
+            to_out = r == 0 and line.lstrip().startswith("{")
+            (sys.stdout if to_out else sys.stderr).write(line if to_out else "[rank %d] %s" % (r, line))
+            (sys.stdout if to_out else sys.stderr).flush()
+    pumps = [threading.Thread(target=pump, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs)]
+    for t in pumps:
+        t.start()
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad and failed_at is None:
+            failed_at, rc = time.time(), bad[0]
+            print("bench.py: a rank exited with code %d; waiting up to 30 s for the others" % rc, file=sys.stderr)
+        if failed_at is not None and time.time() - failed_at > 30:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                                   # this exact child, by PID
+            time.sleep(2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for t in pumps:
+        t.join(5)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    return rc
 
 
 def main():
@@ -221,7 +289,14 @@ def main():
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded end-to-end registration when N > 1")
     ap.add_argument("--sharded-timeout", type=int, default=150, help="watchdog of the sharded leg, seconds")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL; one GPU per rank) | gloo (rehearsal: all ranks on GPU 0)")
+    ap.add_argument("--shard-ramp", type=int, default=32, help="sharded legs: a rank's step follows the single-GPU driver's ramp of rotation parents per batch, 8 -> this (0 = a fixed 8 per step)")
+    ap.add_argument("--deep-mse", type=float, default=3e-5, help="mse threshold of the deep strong-scaling leg (bunny; below the optimum's error: the search has to PROVE the optimum, 6.7 s on one GPU); 0 = skip")
+    ap.add_argument("--e2e-repeats", type=int, default=5, help="registrations of the end-to-end leg (min / median / spread reported)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: be the launcher.  Nothing above or in spawn_ranks initialises the GPU; the ranks are children, not re-executions
+        sys.exit(spawn_ranks(args.gpus, args.backend))
 
     import torch
     import torch.distributed as dist
@@ -229,7 +304,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly (no WORLD_SIZE) to let bench.py start the ranks" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     if args.backend == "gloo":
@@ -239,7 +314,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        tmo = datetime.timedelta(seconds=300)          # a failed rank must not hang the others for the default 10+ min
+        tmo = datetime.timedelta(seconds=600)          # a failed rank must not hang the others for the default 10+ min (rank 0's single-rank legs -- probes, CPU baseline, S2 -- take ~1 min while the others wait)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
         else:
@@ -403,11 +478,10 @@ def main():
                "pose": "ICP-only local minimum reached from identity (205 forced iterations)"}
         pmc_icp = _profile("pmc_icp.json")
         if args.workload == "bunny" and pmc_icp:
-            with open(pmc_icp) as f:
-                pj = json.load(f)
-            tr = pj["hbm_bytes_per_pass_corrected"]
+            tr, prov, pj = _profile_traffic(pmc_icp, "hbm_bytes_per_pass_corrected", lib.goicp_kernel_source_hash().decode())
             icp["roofline_nn"].update({"traffic": tr, "traffic_source": "profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE per pass, fabric side of L2)" % os.path.basename(pmc_icp),
-                                       "hbm_frac": round(tr / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "pmc_reading": pj.get("reading")})
+                                       "hbm_frac": None if tr is None else round(tr / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "pmc_reading": pj.get("reading")})
+            icp["roofline_nn"].update(prov)
 
     out = None
     if rank == 0:
@@ -437,13 +511,11 @@ def main():
         # HBM-side traffic of the same launch: PMC counters cannot be read from inside this process; they are
         # collected with `rocprofv3 --pmc` on this exact command (separate passes for FETCH_SIZE and WRITE_SIZE,
         # gfx950 x2 correction on FETCH_SIZE) and committed under profiles/
-        traffic, traffic_src, limiter = None, None, None
+        traffic, traffic_src, limiter, traffic_prov = None, None, None, {}
         for pmc in (_profile("pmc_bounds_%s.json" % args.workload),):
             cand = os.path.basename(pmc) if pmc else ""
             if cand and Bc == 65536 and args.dt_size == (300 if args.workload != "s2" else 512):
-                with open(pmc) as f:
-                    j = json.load(f)
-                traffic = j["hbm_bytes_per_launch_corrected"]
+                traffic, traffic_prov, j = _profile_traffic(pmc, "hbm_bytes_per_launch_corrected", lib.goicp_kernel_source_hash().decode())
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; fabric side of L2, Infinity-Cache hits included: an upper bound on HBM bytes)" % cand
                 limiter = j.get("limiter")
                 break
@@ -465,6 +537,12 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_launch_as_built": built_bytes,
                     "cube_bounds_per_s_kernel": round(Bc / launch_s, 1)}
         roofline["frac_of_lines16_l1_probe"] = round(glook / probe.get("lines16_l1", float("nan")), 4)
+        roofline.update(traffic_prov)
+        # SURVEY 8(d)'s own recipe, so that its answer is in the line and not only in prose: algorithmic bytes (16 N ub pass / 20 N lb pass, no
+        # reuse) / launch time / 8 TB/s.  Above 1 at these sizes -- void as a fraction: both operands are cache-resident (L2 hit 95 %) and a
+        # point is loaded once per 8 sibling cubes; `frac` (measured gather ceiling) and hbm.frac (counter traffic) are the ones that bind
+        roofline["frac_survey_model"] = round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["frac_survey_model_is"] = "SURVEY 8(d) bytes (16 N / 20 N per cube bound, no reuse) / launch time / 8 TB/s -- void when > 1: cache-resident operands + sibling reuse (a point's 16 B serve 8 cubes)"
         if limiter:
             roofline["limiter"] = limiter
         if args.workload == "s2" and traffic is not None:
@@ -529,11 +607,17 @@ def main():
             eng = pkg.FastGoICP(model, data, 1e-3, dt_size=V, dt_layout=args.dt_layout, device=local_rank, kd_gpu_build=args.kd_gpu_build,
                                 bounds_fp16=args.bounds_fp16, device_queues=args.device_queues, icp_nn_cache=args.icp_nn_cache, flow=args.flow,
                                 **({"icp_fused": args.icp_fused} if args.icp_fused >= 0 else {}))
-            t1 = time.perf_counter()
-            eng.run()
-            wall = time.perf_counter() - t1
+            walls = []
+            for _ in range(max(1, args.e2e_repeats)):          # the same registration, repeated on the same engine (every run starts from scratch: register_begin)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.run()
+                walls.append(time.perf_counter() - t1)
+            wall = float(np.median(walls))
             r = eng.registration.poll()
-            e2e = {"register_s": round(wall, 4), "sse": float(r.best_sse), "cube_bounds": int(r.counters.cubes),
+            e2e = {"register_s": round(wall, 4), "register_s_is": "median of %d runs" % len(walls), "register_s_min": round(min(walls), 4), "register_s_max": round(max(walls), 4),
+                   "register_s_spread_pct": round(100 * (max(walls) - min(walls)) / wall, 2), "register_s_runs": [round(w, 4) for w in walls],
+                   "sse": float(r.best_sse), "cube_bounds": int(r.counters.cubes),
                    "cube_bounds_per_s": round(r.counters.cubes / wall, 1), "rot_pops": int(r.counters.rot_pops),
                    "trans_pops": int(r.counters.trans_pops), "icp_iters": int(r.counters.icp_iters),
                    "dt_build_ms": round(r.dt_build_ms, 2), "engine_create_s": round(t_create, 3)}
@@ -546,7 +630,7 @@ def main():
                             "trans_error": round(float(np.linalg.norm(np.asarray(r.optT, np.float64) - np.array(gj["t"]))), 6),
                             "pose_error_vs": "the reference CPU Go-ICP's optimum (tests/golden/e2e_bunny_full.json); tolerance 2e-3 rad / 2e-3 (SURVEY 8c)"})
         cpu = None
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:                      # rank 0's host cores, at every N (the other ranks wait at the next collective)
             c = cpu_baseline(reg, model, data)
             port = {"port_value": round(c["1thread"], 1), "port_allcores_value": round(c["allcores"], 1), "port_allcores": c["ncores"],
                     "port_sample": "oracle cube_bound (restated InnerBnB body) on the same DT/cloud, ~6 s per leg, alternating ub/lb batches of 64 cubes; all-core leg = OpenMP over cubes",
@@ -579,18 +663,23 @@ def main():
     # ---- the HBM-bound configuration (BASELINE configs[4] per GPU: N = M = 1 M, DT 512^3 = 537 MB, beyond the Infinity Cache):
     # a few launches of the same 65 536-cube batch, and the HBM roofline of that launch = fabric-side bytes (PMC, committed
     # profile of this same batch) / the launch time measured HERE / 8 TB/s
-    if rank == 0 and world == 1 and args.workload == "bunny" and args.s2_steps > 0:
+    if rank == 0 and args.workload == "bunny" and args.s2_steps > 0:
         try:
             out["s2"] = s2_leg(pkg, B, lib, args, dev, torch)
         except Exception as e:      # reported, never fatal for the headline line
             out["s2"] = {"error": repr(e)}
 
-    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the best error +
-    # winner's pose between steps, rebalancing) on BASELINE configs[3]: the reference's own spanner scans (committed fixtures
-    # tests/golden/spanner_*.f32: noisy_flipped_model_spanner.ply / rotated_model_spanner.ply x 0.02, 150 000 points each,
-    # mse 1e-4), bulk-synchronous and with the one-step-stale exchange ----
+    # ---- N > 1: the sharded search itself (rotation cubes dealt to the ranks, RCCL min-all-reduce of the best error + winner's pose
+    # between steps, rebalancing; csrc/shard.cpp over csrc/rccl_comm.cpp), two workloads:
+    #   spanner  BASELINE configs[3]: the reference's own scans (tests/golden/spanner_*.f32: noisy_flipped_model_spanner.ply /
+    #            rotated_model_spanner.ply x 0.02, 150 000 points each, mse 1e-4) -- 64 rotation nodes, ~20 ms on ONE GPU: the
+    #            latency-floor case (what an exchange costs), bulk-synchronous and with the one-step-stale exchange;
+    #   deep     the bunny at --deep-mse (3e-5: below the optimum's error, so the search has to PROVE the optimum -- 6.7 s and 340 M
+    #            cube bounds on one GPU): the strong-scaling case.  A world-1 run of the same problem is timed in this same invocation
+    #            (rank 0 alone, the others wait), so `speedup_vs_world1` and `work_inflation` (cube bounds of all ranks / world-1's)
+    #            are measured, not quoted.
     sharded_res = None
-    sharded_hung = False
+    sharded_failed = False
     if world > 1 and not args.no_sharded:
         box = {}
 
@@ -621,34 +710,67 @@ def main():
                     exchange = "library protocol over RCCL (ncclAllReduce MIN of 6 packed u64 + ncclBroadcast of R|t on change + rebalancing; per-collective deadline)"
                 else:
                     comm = sharded.torch_comm_ops(dist, torch.device("cpu"))
-                    exchange = "library protocol over torch.distributed gloo (rehearsal)"
-                res = {"workload": "BASELINE configs[3] spanner_goicp: N=M=150000 (the reference's noisy / rotated scans x 0.02), mse 1e-4, DT 300^3", "exchange": exchange}
-                for mode, stale in (("bulk_synchronous", False), ("stale_exchange", True)):
-                    eng = pkg.FastGoICP(tgt, srcc, 1e-4, dt_size=300, device=local_rank)
+                    exchange = "library protocol over torch.distributed gloo (rehearsal: every rank on GPU 0)"
+                ramp = max(0, args.shard_ramp)
+                step_rule = "8 rotation parents in the first step, doubling per step up to %d (the single-GPU driver's ramp), one exchange per batch" % ramp if ramp > 8 else "8 rotation parents per step"
+
+                def one(t_cloud, s_cloud, mse, stale):
+                    eng = pkg.FastGoICP(t_cloud, s_cloud, mse, dt_size=300, device=local_rank)
                     dist.barrier()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=8, stale=stale)
+                    lstats = sharded.run_sharded_library(eng, comm, rot_pops_per_step=8, stale=stale, ramp_to=ramp)
                     wall = time.perf_counter() - t1
                     sse, Rr, tr = eng.pose()
-                    Rr = Rr.reshape(3, 3)
                     c = eng.counters
-                    tot = torch.tensor([float(c.cubes), float(c.rot_pops), float(lstats["steps_idle"])], dtype=torch.float64, device=dev)
+                    tot = torch.tensor([float(c.cubes), float(c.rot_pops), float(lstats["steps_idle"]), float(c.icp_iters)], dtype=torch.float64, device=dev)
                     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-                    mx = torch.tensor([wall, lstats["wait_ms"], lstats["step_ms"]], dtype=torch.float64, device=dev)
+                    mx = torch.tensor([wall, lstats["wait_ms"], lstats["step_ms"], float(c.cubes)], dtype=torch.float64, device=dev)
                     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                    ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
-                    res[mode] = {"wall_s": round(float(mx[0].item()), 4), "sse": float(sse), "sse_threshold": float(eng.sse_threshold),
-                                 "cube_bounds_all_ranks": int(tot[0].item()), "rot_pops_all_ranks": int(tot[1].item()),
-                                 "steps": lstats["steps"], "exchanges": lstats["exchanges"], "pose_broadcasts": lstats["broadcasts"], "donations": lstats["donations"],
-                                 "idle_steps_all_ranks": int(tot[2].item()), "max_rank_wait_ms": round(float(mx[1].item()), 3), "max_rank_step_ms": round(float(mx[2].item()), 3),
-                                 "rot_error_rad_vs_ground_truth": round(ang, 5), "trans_error_vs_ground_truth": round(float(np.linalg.norm(tr - tgt_t)), 5)}
+                    out_ = {"wall_s": round(float(mx[0].item()), 4), "sse": float(sse), "sse_threshold": float(eng.sse_threshold),
+                            "cube_bounds_all_ranks": int(tot[0].item()), "cube_bounds_busiest_rank": int(mx[3].item()), "rot_pops_all_ranks": int(tot[1].item()), "icp_iters_all_ranks": int(tot[3].item()),
+                            "steps": lstats["steps"], "exchanges": lstats["exchanges"], "pose_broadcasts": lstats["broadcasts"], "donations": lstats["donations"],
+                            "idle_steps_all_ranks": int(tot[2].item()), "max_rank_wait_ms": round(float(mx[1].item()), 3), "max_rank_step_ms": round(float(mx[2].item()), 3)}
                     eng.registration.close()
+                    return out_, Rr.reshape(3, 3), tr
+
+                res = {"exchange": exchange, "step": step_rule,
+                       "spanner": {"workload": "BASELINE configs[3] spanner_goicp: N=M=150000 (the reference's noisy / rotated scans x 0.02), mse 1e-4, DT 300^3 -- 64 rotation nodes, ~20 ms on one GPU: the latency-floor case"}}
+                for mode, stale in (("bulk_synchronous", False), ("stale_exchange", True)):
+                    r_, Rr, tr = one(tgt, srcc, 1e-4, stale)
+                    ang = float(2 * np.arcsin(min(1.0, np.linalg.norm(Rr.astype(np.float64) - Rgt) / (2 * np.sqrt(2)))))
+                    r_.update({"rot_error_rad_vs_ground_truth": round(ang, 5), "trans_error_vs_ground_truth": round(float(np.linalg.norm(tr - tgt_t)), 5)})
+                    res["spanner"][mode] = r_
+                if args.deep_mse > 0:
+                    bm = np.fromfile(os.path.join(g, "model_bunny.f32"), dtype="<f4").reshape(-1, 3)
+                    bd = np.fromfile(os.path.join(g, "data_bunny.f32"), dtype="<f4").reshape(-1, 3)
+                    w1 = torch.zeros(5, dtype=torch.float64, device=dev)
+                    if rank == 0:
+                        e1 = pkg.FastGoICP(bm, bd, args.deep_mse, dt_size=300, device=local_rank)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        e1.run()
+                        w1[0] = time.perf_counter() - t1
+                        c1 = e1.counters
+                        w1[1], w1[2], w1[3], w1[4] = float(c1.cubes), float(c1.rot_pops), float(e1.get_best_error()), float(c1.icp_iters)
+                        e1.registration.close()
+                    dist.broadcast(w1, src=0)
+                    wall1, cubes1, rot1, sse1 = float(w1[0].item()), float(w1[1].item()), float(w1[2].item()), float(w1[3].item())
+                    d_, _, _ = one(bm, bd, args.deep_mse, False)
+                    d_.update({"workload": "bunny (N=30379, M=35947, DT 300^3) at mse %g: SSEThresh below the optimum's error, so no early exit -- the search proves the optimum (strong scaling: the same problem at every N)" % args.deep_mse,
+                               "world1": {"wall_s": round(wall1, 4), "cube_bounds": int(cubes1), "rot_pops": int(rot1), "sse": sse1, "is": "the same problem on rank 0 alone (goicp_register, no exchange), timed in this invocation"},
+                               "speedup_vs_world1": round(wall1 / d_["wall_s"], 3), "work_inflation": round(d_["cube_bounds_all_ranks"] / max(cubes1, 1.0), 4),
+                               "rot_nodes_inflation": round(d_["rot_pops_all_ranks"] / max(rot1, 1.0), 4),
+                               "parallel_efficiency": round(wall1 / d_["wall_s"] / world, 3),
+                               "same_optimum": bool(abs(d_["sse"] - sse1) <= 1e-3 * max(sse1, 1e-6) + d_["sse_threshold"])})
+                    res["deep"] = d_
                 if args.backend == "nccl":
                     B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
                 box['res'] = res
-            except Exception as e:      # reported; whether it is fatal is decided below
-                box['res'] = {"error": repr(e)}
+            except Exception as e:      # reported in the line; fatal for the exit code (below)
+                import traceback
+                traceback.print_exc()
+                box['res'] = dict(box.get('res') or {}, error=repr(e))
                 box['failed'] = True
 
         # the leg runs under a watchdog as a second line of defence behind the library's own per-collective deadlines
@@ -657,11 +779,11 @@ def main():
         th.start()
         th.join(args.sharded_timeout)
         if th.is_alive():
-            sharded_hung = True
+            sharded_failed = True
             sharded_res = {"error": "no result within %d s (watchdog)" % args.sharded_timeout}
         else:
             sharded_res = box.get('res')
-            sharded_hung = bool(box.get('failed')) and "TIMEOUT" in str(sharded_res)
+            sharded_failed = bool(box.get('failed'))
 
     if rank == 0:
         out["e2e_sharded"] = sharded_res
@@ -674,10 +796,10 @@ def main():
                 return [_clean(v) for v in o]
             return o
         print(json.dumps(_clean(out), allow_nan=False), flush=True)
-    if sharded_hung:
-        # a rank was lost (a collective missed its deadline / is still stuck): the line is out with its `error`, and the
-        # process reports FAILURE -- leave without the teardown (it would hang in the same place); the launcher then starts
-        # a fresh process, never a re-exec
+    if sharded_failed:
+        # ANY failure of the sharded leg on this rank (a lost rank / missed deadline / device error / exception) is fatal: the line
+        # is out with its `error`, and the process reports FAILURE -- without the teardown (a collective may be stuck in it).  The
+        # launcher ends the other ranks (spawn_ranks here, torchrun likewise) and starts fresh processes next time, never a re-exec
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(1)

@@ -11,3 +11,16 @@ from . import binding  # noqa: F401
 from .binding import GoicpError, build_library, library_path, load_library  # noqa: F401
 from .fgoicp import (Config, FastGoICP, IterativeClosestPoint3D, Registration, RotNode, TransNode,  # noqa: F401
                      load_cloud)
+
+
+def kernel_source_hash():
+    """The hash goicp_kernel_source_hash() reports, recomputed from the sources in the tree (csrc/Makefile: sha256 over device.hip,
+    bnbqueue.hip, kdbuild.hip, device.hpp, first 16 hex digits): a library that is out of date with its sources shows here."""
+    import hashlib
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for n in ("device.hip", "bnbqueue.hip", "kdbuild.hip", "device.hpp"):
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]

@@ -74,7 +74,7 @@ class CShardStats(C.Structure):
 
 
 class CShardOptions(C.Structure):
-    _fields_ = [("rot_pops_per_step", C.c_int32), ("rebalance", C.c_int32), ("stale_exchange", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("rot_pops_per_step", C.c_int32), ("rebalance", C.c_int32), ("stale_exchange", C.c_int32), ("ramp_to", C.c_int32)]
 
 
 _fpp = C.POINTER(C.c_float)
@@ -98,6 +98,7 @@ _fp, _vp = C.POINTER(C.c_float), C.c_void_p
 SYMBOLS = {
     "goicp_last_error": (C.c_char_p, []),
     "goicp_abi_version": (C.c_int, []),
+    "goicp_kernel_source_hash": (C.c_char_p, []),
     "goicp_config_load": (C.c_int, [C.c_char_p, C.POINTER(CConfig)]),
     "goicp_cloud_load": (C.c_int, [C.c_char_p, C.c_float, C.c_float, C.c_uint64, C.POINTER(_fp), C.POINTER(C.c_size_t)]),
     "goicp_cloud_free": (None, [_fp]),
@@ -108,6 +109,7 @@ SYMBOLS = {
     "goicp_set_progress_callback": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     "goicp_probe_gather": (C.c_int, [_vp, C.c_int32, C.c_size_t, C.POINTER(C.c_double)]),
     "goicp_debug_kabsch": (C.c_int, [_fp, _fp]),
+    "goicp_debug_queue_expand": (C.c_int, [C.c_void_p, _fp, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, _fp, C.POINTER(C.c_int32)]),
     "goicp_debug_bounds_tile": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.POINTER(C.c_uint32)]),
     "goicp_debug_cache_hits": (C.c_int, [_vp, _fp, _fp, C.POINTER(C.c_int64)]),
     "goicp_create": (C.c_int, [C.POINTER(CParams), _fp, C.c_size_t, _fp, C.c_size_t, C.POINTER(_vp)]),

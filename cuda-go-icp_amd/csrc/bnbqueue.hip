@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned node_key(float lb, int depth)
 }
 __device__ __forceinline__ bool in_box(const QParams& qp, float x, float y, float z, float w)
 {
-	return x + w > qp.lo[0] && x < qp.hi[0] && y + w > qp.lo[1] && y < qp.hi[1] && z + w > qp.lo[2] && z < qp.hi[2];
+	return cube_in_range(x, y, z, w, qp.lo, qp.hi);          // half-open cube against the closed range: the range's high face is inclusive (device.hpp)
 }
 
 }  // namespace
@@ -462,7 +462,10 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			sh.parent_off = atomicAdd(&ctl->n_tile_groups[parity], n_sel);
 			atomicAdd(&ctl->tile_total, n_sel);
 			const int seg0 = atomicAdd(&ctl->n_tile_segs[parity], nseg);
-			for (int k = 0; k < nseg; k++) tile.segs[parity][seg0 + k] = TileSeg{sh.parent_off + 64 * k, min(64, n_sel - 64 * k), S->rot};
+			// the segment list holds list_cap / 64 + (search slots) entries: sum ceil(n_i / 64) <= sum n_i / 64 + searches, and sum n_i <= list_cap
+			// is checked below -- so this cannot trip while the host sized the lists; if it ever does, nothing is written past them
+			if (seg0 + nseg > qp.seg_cap || sh.parent_off + n_sel > qp.list_cap) sh.parent_off = qp.list_cap;       // -> the overflow exit below
+			else for (int k = 0; k < nseg; k++) tile.segs[parity][seg0 + k] = TileSeg{sh.parent_off + 64 * k, min(64, n_sel - 64 * k), S->rot};
 		} else
 			sh.parent_off = atomicAdd(&ctl->n_groups[parity], n_sel);
 		atomicAdd(&ctl->n_active[parity], 1);

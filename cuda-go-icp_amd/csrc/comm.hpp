@@ -14,6 +14,11 @@ constexpr uint32_t kCommMagic = 0x43494f47u;     // "GOIC"
 
 int comm_default_timeout_ms();                   // GOICP_COMM_TIMEOUT_MS, else 60 000
 int comm_set_timeout_ms(goicp_comm_ops* comm, int ms);
+// A communicator of the library is recognised by its all-reduce FUNCTION (registered here by the kind that owns it), never by
+// peeking into ctx: the ABI lets a caller bring its own communicator, whose ctx may be anything -- or nothing readable.
+using CommAllreduceFn = int (*)(void*, uint64_t*, size_t);
+void comm_register_library_kind(CommAllreduceFn fn);
+bool comm_is_library_kind(const goicp_comm_ops* comm);
 
 int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats);
 int thread_comm_create(int world, goicp_comm_ops* out);

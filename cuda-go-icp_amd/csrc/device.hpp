@@ -7,6 +7,18 @@
 
 namespace goicp {
 
+// Search-range cull shared by the host queues (engine.hpp) and the device queues (bnbqueue.hip): the half-open cube
+// [x, x+w)^3 against the closed range [lo, hi] -- low face of the range exclusive for a cube that only ends there,
+// high face inclusive for the cube that starts there ([params.rotation] / [params.translation] of the reference's
+// configs, src/common.h:157-169).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool cube_in_range(float x, float y, float z, float w, const float lo[3], const float hi[3])
+{
+	return x + w > lo[0] && x <= hi[0] && y + w > lo[1] && y <= hi[1] && z + w > lo[2] && z <= hi[2];
+}
+
 // Distance transform of the target cloud, resident in HBM.
 //   layout 0: linear  [z][y][x], x fastest                       (reference order, jly_3ddt.h:53-79)
 //   layout 1: bricked 4x4x4 voxels per 256-B brick, bricks [bz][by][bx]; a surface patch touched
@@ -139,6 +151,7 @@ struct QParams {
 	int32_t K;                      // expansions per search and round (<= kQueueMaxPop)
 	int32_t kmax;                   // cap on K after the kernel's own widening: searches still running x kmax fits the round's lists
 	int32_t list_cap;               // expansions the round's lists hold (a round that would exceed it flags overflow: host fallback)
+	int32_t seg_cap;                // segments the tile list holds (list_cap / 64 + search slots: every search adds at most one partial segment)
 	float root_x, root_y, root_z, root_w;
 	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
 	int32_t cap;                    // nodes a queue may hold (<= kQueueCap; smaller values only to exercise the overflow path)

@@ -963,6 +963,77 @@ void Engine::debug_bounds_tile(const float* rots9, const float* parents4, int ns
 	HIPCHK(hipMemcpy(stats, d_stats.p, sizeof(unsigned) * 2, hipMemcpyDeviceToHost));
 }
 
+void Engine::debug_queue_expand(const float R[9], int level, const float* parents4, int n, float* ub0, float* lb0, float* ub1, float* lb1, int info[2])
+{
+	DeviceGuard guard(dev_);
+	if (n < 1 || n > kQueueRoundPop) throw std::invalid_argument("goicp: debug_queue_expand takes 1..128 nodes");
+	if (!(p_.device_queues && p_.trans_batch > 1 && p_.wide_children)) throw std::invalid_argument("goicp: debug_queue_expand needs the device-queue configuration");
+	if (inliers_ < (int)N_) throw std::invalid_argument("goicp: debug_queue_expand: untrimmed engines only");
+	ensure_queues(2);
+	ensure_batch(1, 1);
+	std::memcpy(h_rots_[0].r, R, sizeof(float) * 9);
+	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9), hipMemcpyHostToDevice, stream_));
+	const bool twins = p_.twin_fusion && d_qpsearch_[0] != nullptr;
+	// two searches whose queues hold exactly the given nodes (lower bound 0: all of them pass the stop rule against a huge incumbent and,
+	// n <= K, all are selected; the list keeps the queue order)
+	std::vector<QNode> nodes((size_t)n);
+	for (int i = 0; i < n; i++) nodes[(size_t)i] = QNode{parents4[4 * i], parents4[4 * i + 1], parents4[4 * i + 2], parents4[4 * i + 3], 0.f, 0.f};
+	for (int s = 0; s < 2; s++) {
+		QSearch& q = h_qsearch_[s];
+		std::memset(&q, 0, sizeof(q));
+		q.best = 1e30f; q.coeff = s ? rot_coeff(level) : 0.f; q.rot = 0; q.count = n; q.min_ub = INFINITY; q.twin = twins ? (s ^ 1) : -1;
+		HIPCHK(hipMemcpyAsync(d_qnodes_ + (size_t)s * kQueueCap, nodes.data(), sizeof(QNode) * (size_t)n, hipMemcpyHostToDevice, stream_));
+	}
+	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * 2, hipMemcpyHostToDevice, stream_));
+	std::memset(h_qctl_, 0, sizeof(QCtl));
+	h_qctl_->tile_chunks = 1;
+	HIPCHK(hipMemcpyAsync(d_qctl_, h_qctl_, sizeof(QCtl), hipMemcpyHostToDevice, stream_));
+	QParams qp = queue_params();
+	qp.K = std::max(n, 1); qp.kmax = kQueueRoundPop; qp.tile_on = 0; qp.stale_widen = 0; qp.stale_compact = 0;
+	const int parity = 0, max_groups = 2 * n;
+	HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, 2, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, nullptr,
+	                        twins ? d_qpsearch_[parity] : nullptr));
+	HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
+	                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, nullptr));
+	HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * 2, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipStreamSynchronize(stream_));
+	if (h_qctl_->overflow || h_qctl_->n_groups[parity] != 2 * n || h_qsearch_[0].n_parents != n || h_qsearch_[1].n_parents != n)
+		throw std::logic_error("goicp: debug_queue_expand: the round did not list every node");
+	const int chunks = h_qctl_->chunks;
+	info[0] = chunks; info[1] = twins ? 1 : 0;
+	std::vector<ParentRec> listed((size_t)2 * n);
+	HIPCHK(hipMemcpy(listed.data(), d_qparents_[parity], sizeof(ParentRec) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+	std::vector<float> ub((size_t)16 * n), lb((size_t)16 * n), part;
+	if (chunks > 1) {
+		part.resize((size_t)2 * n * chunks * 2 * kGroup);
+		HIPCHK(hipMemcpy(part.data(), d_qscratch_, sizeof(float) * part.size(), hipMemcpyDeviceToHost));
+	} else {
+		HIPCHK(hipMemcpy(ub.data(), d_qub_, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(lb.data(), d_qlb_, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
+	}
+	for (int s = 0; s < 2; s++) {
+		const int off = h_qsearch_[s].parent_off;
+		float* ou = s ? ub1 : ub0; float* ol = s ? lb1 : lb0;
+		for (int e = 0; e < n; e++) {
+			const ParentRec& pr = listed[(size_t)off + e];
+			if (pr.x != parents4[4 * e] || pr.y != parents4[4 * e + 1] || pr.z != parents4[4 * e + 2] || pr.w != parents4[4 * e + 3])
+				throw std::logic_error("goicp: debug_queue_expand: the list is not in queue order");
+			for (int c = 0; c < kGroup; c++) {
+				if (chunks > 1) {
+					// the chunk partials, added in chunk order as the next round's digest does (bnbqueue.hip)
+					float a = 0.f, b = 0.f;
+					for (int j = 0; j < chunks; j++) {
+						const float* sp = part.data() + ((size_t)(off + e) * chunks + j) * (2 * kGroup);
+						a += sp[c]; b += sp[kGroup + c];
+					}
+					ou[8 * e + c] = a; ol[8 * e + c] = b;
+				} else { ou[8 * e + c] = ub[(size_t)8 * (off + e) + c]; ol[8 * e + c] = lb[(size_t)8 * (off + e) + c]; }
+			}
+		}
+	}
+}
+
 long long Engine::debug_cache_hits(const float R[9], const float t[3])
 {
 	// two scoring passes at the same pose: the second one's queries should all hit the neighbour cache
@@ -1035,6 +1106,8 @@ void Engine::ensure_queues(size_t nsearch)
 	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
 	const size_t max_groups = cap * kQueueRoundPop;          // what the round's lists hold; QParams::kmax keeps (searches running) x (their steps) inside
 	q_list_cap_ = (int)max_groups;
+	// segments (<= 64 expansions of one search) of the tile list: every search contributes floor(n / 64) full ones and at most one partial
+	q_seg_cap_ = (int)(max_groups / 64 + cap);
 	HIPCHK(hipMalloc(&d_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipHostMalloc(&h_qsearch_, sizeof(QSearch) * cap));
 	HIPCHK(hipMalloc(&d_qnodes_, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
@@ -1065,11 +1138,11 @@ void Engine::ensure_queues(size_t nsearch)
 		// the second expansion list of a round (LDS-staged DT tiles): same capacity as the direct list
 		for (int k = 0; k < 2; k++) {
 			HIPCHK(hipMalloc(&qtile_.parents[k], sizeof(ParentRec) * max_groups));
-			HIPCHK(hipMalloc(&qtile_.segs[k], sizeof(TileSeg) * 2 * cap));
+			HIPCHK(hipMalloc(&qtile_.segs[k], sizeof(TileSeg) * q_seg_cap_));
 		}
 		HIPCHK(hipMalloc(&qtile_.ub, sizeof(float) * max_groups * kGroup));
 		HIPCHK(hipMalloc(&qtile_.lb, sizeof(float) * max_groups * kGroup));
-		HIPCHK(hipMalloc(&qtile_.scratch, sizeof(float) * bounds_tile_queue_scratch_floats((int)(2 * cap))));
+		HIPCHK(hipMalloc(&qtile_.scratch, sizeof(float) * bounds_tile_queue_scratch_floats(q_seg_cap_)));
 	}
 	if (!d_qctl_) {
 		HIPCHK(hipMalloc(&d_qctl_, sizeof(QCtl)));
@@ -1571,7 +1644,7 @@ QParams Engine::queue_params() const
 	qp.stale_compact = p_.adaptive_k && p_.stale_widen ? p_.stale_compact : 0;
 
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueRoundPop);
-	qp.kmax = kQueueRoundPop; qp.list_cap = q_list_cap_;     // any number of searches fits; run_inner_device raises kmax for the last few
+	qp.kmax = kQueueRoundPop; qp.list_cap = q_list_cap_; qp.seg_cap = q_seg_cap_;     // any number of searches fits; run_inner_device raises kmax for the last few
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
 	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
@@ -1661,7 +1734,9 @@ int Engine::flow_step(int max_rot_pops)
 		const double t0 = now_ms();
 		QParams qr = qp;
 		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueRoundPop : (flow_active_ <= 64 ? std::min(kQueueRoundPop, 2 * qp.K) : qp.K);
-		const int max_groups = q_hi_ * qr.K;
+		// most the round can list: the queue kernel widens a stale search's step up to x4 (stale_widen), as in run_inner_device --
+		// sizing the evaluation's grid by q_hi_ * K left the expansions listed beyond it unevaluated in trimmed runs (one workgroup each)
+		const int max_groups = (int)std::min<size_t>((size_t)q_hi_ * (size_t)std::min(qr.kmax, 4 * qr.K), (size_t)q_list_cap_);
 		for (int r = 0; r < 3; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0], &d_qctl_->chunks,

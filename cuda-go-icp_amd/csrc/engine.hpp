@@ -125,6 +125,13 @@ public:
 	// measured ceiling of the gather path (4-byte loads into the resident DT): lookups/s; mode 0 coalesced, 1 divergent
 	double probe_gather(int mode, size_t window_bytes);
 	long long debug_cache_hits(const float R[9], const float t[3]);
+	// test: the n (<= 128) given translation nodes (parents4: corner xyz + width) expanded by ONE round of the device-resident queues -- an
+	// upper-bound search (coeff 0) and a lower-bound search (rotation level `level`) of the same rotation, twins of each other, both listing
+	// all n nodes: the round the outer search's lock-step batches run (selection by bnb_queue_kernel, evaluation by bounds_queue_kernel with
+	// twin fusion when the engine has it on).  out[pass][8 n]: the children's bounds of pass 0 (upper-bound search) and pass 1
+	// (lower-bound search), in the order of parents4.  info[0] = point chunks the evaluation split the cloud into, info[1] = 1 when the
+	// twin lists were in use.
+	void debug_queue_expand(const float R[9], int level, const float* parents4, int n, float* ub0, float* lb0, float* ub1, float* lb1, int info[2]);
 	// measurement / test: the 8 children of nseg x n expansions (segment i: rotation i, parents4[(i*n + e)*4 ..] = corner xyz + width) through
 	// the LDS-tile kernel and through the direct kernel; out arrays hold 8*nseg*n floats each; ms[0] tile, ms[1] direct (per launch)
 	void debug_bounds_tile(const float* rots9, const float* parents4, int nseg, int n, int level, int chunks, float* ub_tile, float* lb_tile,
@@ -202,10 +209,11 @@ private:
 		explicit DeviceGuard(int dev);
 		~DeviceGuard();
 	};
-	bool in_box(const Node& c, const float lo[3], const float hi[3]) const
-	{
-		return c.x + c.w > lo[0] && c.x < hi[0] && c.y + c.w > lo[1] && c.y < hi[1] && c.z + c.w > lo[2] && c.z < hi[2];
-	}
+	// A cube is the half-open box [x, x+w)^3, a configured range the CLOSED box [lo, hi]: the cube is kept when the two
+	// intersect.  So the high face of a range is inclusive -- a bound (or a fixed value, lo == hi) that coincides with a
+	// split plane belongs to exactly one cube per level, the one that starts there -- and the low face of a cube that
+	// merely ends at lo is not.  Same rule on the device (bnbqueue.hip in_box).
+	bool in_box(const Node& c, const float lo[3], const float hi[3]) const { return cube_in_range(c.x, c.y, c.z, c.w, lo, hi); }
 	void* scratch_bytes(size_t bytes);   // grow-only device scratch for the query / transform operators
 
 	Params p_;
@@ -257,6 +265,7 @@ private:
 	ParentRec* d_qparents_[2] = {nullptr, nullptr};
 	QSort qsort_{};                                     // footprint-ordered items of large rounds (device.hip); order == nullptr: off
 	int q_list_cap_ = 0;                                // expansions the round's lists (parents, bounds, partial sums) hold
+	int q_seg_cap_ = 0;                                 // segments the tile list holds (q_list_cap_ / 64 + search slots)
 	int* d_qpsearch_[2] = {nullptr, nullptr};          // per listed expansion: the search that listed it (twin test of the bound evaluation)
 	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
 	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;

@@ -67,6 +67,10 @@ extern "C" {
 
 const char* goicp_last_error(void) { return g_err.c_str(); }
 int goicp_abi_version(void) { return GOICP_ABI_VERSION; }
+#ifndef GOICP_KERNEL_HASH
+#define GOICP_KERNEL_HASH "unknown"
+#endif
+const char* goicp_kernel_source_hash(void) { return GOICP_KERNEL_HASH; }
 
 int goicp_config_load(const char* toml_path, goicp_config* out)
 {
@@ -208,6 +212,17 @@ int goicp_debug_bounds_tile(goicp_handle h, const float* rots9, const float* par
 {
 	REQUIRE(h && rots9 && parents4 && ub_tile && lb_tile && ub_direct && lb_direct && ms && stats);
 	return guarded([&] { h->e->debug_bounds_tile(rots9, parents4, nseg, n, level, chunks, ub_tile, lb_tile, ub_direct, lb_direct, ms, stats); });
+}
+
+int goicp_debug_queue_expand(goicp_handle h, const float R[9], int32_t level, const float* parents4, int32_t n, float* ub_ubpass, float* lb_ubpass,
+                             float* ub_lbpass, float* lb_lbpass, int32_t info[2])
+{
+	REQUIRE(h && R && parents4 && ub_ubpass && lb_ubpass && ub_lbpass && lb_lbpass && info && n >= 1);
+	return guarded([&] {
+		int inf[2] = {0, 0};
+		h->e->debug_queue_expand(R, level, parents4, n, ub_ubpass, lb_ubpass, ub_lbpass, lb_lbpass, inf);
+		info[0] = inf[0]; info[1] = inf[1];
+	});
 }
 
 int goicp_debug_kabsch(const float H[9], float R[9])
@@ -449,7 +464,7 @@ int eo_end(void* c) { return guarded([&] { E(c)->register_end(); }); }
 void goicp_shard_options_default(goicp_shard_options* out)
 {
 	if (!out) return;
-	out->rot_pops_per_step = 8; out->rebalance = 1; out->stale_exchange = 0; out->reserved = 0;
+	out->rot_pops_per_step = 8; out->rebalance = 1; out->stale_exchange = 0; out->ramp_to = 0;
 }
 
 int goicp_run_sharded_opt(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats)

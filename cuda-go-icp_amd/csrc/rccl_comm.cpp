@@ -73,9 +73,12 @@ int allreduce_min_u64(void* ctx, uint64_t* words, size_t n)
 	if (n * sizeof(uint64_t) > c->cap) return GOICP_ERR_INVALID;
 	DevScope dev(c->device);
 	std::memcpy(c->h_buf, words, n * sizeof(uint64_t));
-	if (hipMemcpyAsync(c->d_buf, c->h_buf, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
-	if (ncclAllReduce(c->d_buf, c->d_buf, n, ncclUint64, ncclMin, c->comm, c->stream) != ncclSuccess) return GOICP_ERR_DEVICE;
-	if (hipMemcpyAsync(c->h_buf, c->d_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
+	// any failure to enqueue leaves the stream in an unknown state: the communicator is broken from here on (destroy then aborts
+	// it instead of waiting on a possibly wedged stream)
+	auto fail = [&] { c->broken = true; (void)hipGetLastError(); return GOICP_ERR_DEVICE; };
+	if (hipMemcpyAsync(c->d_buf, c->h_buf, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail();
+	if (ncclAllReduce(c->d_buf, c->d_buf, n, ncclUint64, ncclMin, c->comm, c->stream) != ncclSuccess) return fail();
+	if (hipMemcpyAsync(c->h_buf, c->d_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return fail();
 	if (const int rc = wait_stream(c)) return rc;
 	std::memcpy(words, c->h_buf, n * sizeof(uint64_t));
 	return GOICP_OK;
@@ -88,9 +91,10 @@ int bcast(void* ctx, void* buf, size_t bytes, int32_t root)
 	if (bytes > c->cap) return GOICP_ERR_INVALID;
 	DevScope dev(c->device);
 	std::memcpy(c->h_buf, buf, bytes);
-	if (hipMemcpyAsync(c->d_buf, c->h_buf, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
-	if (ncclBroadcast(c->d_buf, c->d_buf, bytes, ncclUint8, root, c->comm, c->stream) != ncclSuccess) return GOICP_ERR_DEVICE;
-	if (hipMemcpyAsync(c->h_buf, c->d_buf, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return GOICP_ERR_DEVICE;
+	auto fail = [&] { c->broken = true; (void)hipGetLastError(); return GOICP_ERR_DEVICE; };
+	if (hipMemcpyAsync(c->d_buf, c->h_buf, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail();
+	if (ncclBroadcast(c->d_buf, c->d_buf, bytes, ncclUint8, root, c->comm, c->stream) != ncclSuccess) return fail();
+	if (hipMemcpyAsync(c->h_buf, c->d_buf, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return fail();
 	if (const int rc = wait_stream(c)) return rc;
 	std::memcpy(buf, c->h_buf, bytes);
 	return GOICP_OK;
@@ -112,6 +116,7 @@ int finish(RcclComm* c, int32_t rank, int32_t world, goicp_comm_ops* out)
 	out->ctx = c; out->rank = rank; out->world = world;
 	out->allreduce_min_u64 = &allreduce_min_u64;
 	out->bcast = &bcast;
+	comm_register_library_kind(&allreduce_min_u64);
 	return GOICP_OK;
 }
 

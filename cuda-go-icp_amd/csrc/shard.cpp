@@ -186,7 +186,10 @@ int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, c
 {
 	if (!eng || !comm || !opt || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || opt->rot_pops_per_step < 1) return GOICP_ERR_INVALID;
 	const int rank = comm->rank, world = comm->world;
-	const int pops = opt->rot_pops_per_step;
+	// step width: fixed, or the single-GPU driver's ramp (engine.cpp register_step: 8, 16, 32, 64 parents per batch) -- a rank
+	// then runs ONE batch per step and exchanges once per batch.  Every rank computes the same sequence.
+	const int pops0 = opt->rot_pops_per_step, ramp_to = opt->ramp_to > pops0 ? opt->ramp_to : 0;
+	int pops = pops0;
 	const bool rebalance = opt->rebalance != 0, stale = opt->stale_exchange != 0 && world > 1;
 	goicp_shard_stats st{};
 	st.failed_rank = -1;
@@ -211,6 +214,7 @@ int run_sharded(const goicp_shard_engine_ops* eng, const goicp_comm_ops* comm, c
 		const double t0 = now_ms();
 		int rc = eng->step(eng->ctx, pops, &ss);
 		st.step_ms += now_ms() - t0;
+		if (ramp_to) pops = std::min(ramp_to, pops * 2);
 		if (rc == GOICP_OK) rc = eng->pose(eng->ctx, &s.sse, s.R, s.t);
 		if (rc != GOICP_OK) { local_rc = s.local_rc = rc; s.sse = inf; return s; }
 		st.steps++;
@@ -419,11 +423,29 @@ int thread_bcast(void* ctx, void* buf, size_t bytes, int32_t root)
 
 int comm_default_timeout_ms() { return env_timeout_ms(); }
 
+namespace {
+std::mutex g_kinds_m;
+std::vector<CommAllreduceFn> g_kinds;
+}  // namespace
+
+void comm_register_library_kind(CommAllreduceFn fn)
+{
+	std::lock_guard<std::mutex> lk(g_kinds_m);
+	if (std::find(g_kinds.begin(), g_kinds.end(), fn) == g_kinds.end()) g_kinds.push_back(fn);
+}
+bool comm_is_library_kind(const goicp_comm_ops* comm)
+{
+	if (!comm || !comm->allreduce_min_u64) return false;
+	std::lock_guard<std::mutex> lk(g_kinds_m);
+	return std::find(g_kinds.begin(), g_kinds.end(), (CommAllreduceFn)comm->allreduce_min_u64) != g_kinds.end();
+}
+
 int comm_set_timeout_ms(goicp_comm_ops* comm, int ms)
 {
 	if (!comm || !comm->ctx || ms < 1) return GOICP_ERR_INVALID;
+	if (!comm_is_library_kind(comm)) return GOICP_ERR_INVALID;  // a caller's own communicator: its ctx is not ours to read
 	CommHeader* h = static_cast<CommHeader*>(comm->ctx);
-	if (h->magic != kCommMagic) return GOICP_ERR_INVALID;       // not one of the library's communicators
+	if (h->magic != kCommMagic) return GOICP_ERR_INVALID;
 	h->timeout_ms = ms;
 	return GOICP_OK;
 }
@@ -433,6 +455,7 @@ int thread_comm_create(int world, goicp_comm_ops* out)
 	ThreadGroup* g = new (std::nothrow) ThreadGroup;
 	if (!g) return GOICP_ERR_INTERNAL;
 	g->world = world; g->refs = world;
+	comm_register_library_kind(&thread_allreduce);
 	for (int r = 0; r < world; r++) {
 		out[r].ctx = new ThreadComm{CommHeader{kCommMagic, env_timeout_ms()}, g, r};
 		out[r].rank = r; out[r].world = world;

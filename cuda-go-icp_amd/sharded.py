@@ -112,7 +112,7 @@ def engine_ops(engine):
     return ops
 
 
-def run_sharded_library(engine_or_ops, comm_ops, rot_pops_per_step=8, rebalance=True, stale=False, raise_on_error=True):
+def run_sharded_library(engine_or_ops, comm_ops, rot_pops_per_step=8, rebalance=True, stale=False, raise_on_error=True, ramp_to=0):
     """Drive one rank through the library's protocol.  engine_or_ops: a fgoicp.FastGoICP (real engine) or a
     CShardEngineOps table.  Returns the goicp_shard_stats as a dict (plus "status": the call's return code when
     raise_on_error is False)."""
@@ -120,7 +120,7 @@ def run_sharded_library(engine_or_ops, comm_ops, rot_pops_per_step=8, rebalance=
     from . import binding as B
     lib = B.load_library()
     st = B.CShardStats()
-    opt = B.CShardOptions(int(rot_pops_per_step), int(bool(rebalance)), int(bool(stale)), 0)
+    opt = B.CShardOptions(int(rot_pops_per_step), int(bool(rebalance)), int(bool(stale)), int(ramp_to))
     if isinstance(engine_or_ops, B.CShardEngineOps):
         rc = lib.goicp_run_sharded_opt(C.byref(engine_or_ops), C.byref(comm_ops), C.byref(opt), C.byref(st))
     else:
@@ -132,7 +132,7 @@ def run_sharded_library(engine_or_ops, comm_ops, rot_pops_per_step=8, rebalance=
     return out
 
 
-def run_thread_ranks(engines, rot_pops_per_step=8, rebalance=True, stale=False, timeout_ms=None, raise_on_error=True):
+def run_thread_ranks(engines, rot_pops_per_step=8, rebalance=True, stale=False, timeout_ms=None, raise_on_error=True, ramp_to=0):
     """len(engines) ranks in ONE process: one host thread per rank over the library's in-process communicator
     (goicp_thread_comm_create) -- N engines on one GPU, or N CPU stand-ins.  engines: fgoicp.FastGoICP objects or
     CShardEngineOps tables.  Returns the per-rank stats (run_sharded_library's dicts)."""
@@ -148,7 +148,7 @@ def run_thread_ranks(engines, rot_pops_per_step=8, rebalance=True, stale=False, 
 
     def worker(r):
         try:
-            stats[r] = run_sharded_library(engines[r], comms[r], rot_pops_per_step, rebalance, stale, raise_on_error)
+            stats[r] = run_sharded_library(engines[r], comms[r], rot_pops_per_step, rebalance, stale, raise_on_error, ramp_to)
         except Exception as e:       # noqa: BLE001 -- reported to the caller below
             errs.append((r, e))
 

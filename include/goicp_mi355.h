@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GOICP_ABI_VERSION 3
+#define GOICP_ABI_VERSION 4
 
 typedef enum goicp_status {
 	GOICP_OK = 0,
@@ -43,6 +43,9 @@ typedef enum goicp_status {
 
 const char* goicp_last_error(void);
 int goicp_abi_version(void);
+/* first 16 hex digits of the SHA-256 over the kernel sources (csrc/device.hip, bnbqueue.hip, kdbuild.hip, device.hpp, in that order)
+ * this library was built from -- measurement hygiene: counter profiles under profiles/ carry the hash they were collected on */
+const char* goicp_kernel_source_hash(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Config  -- replaces class Config (src/common.h:133-180, src/common.cpp:12-77).
@@ -346,12 +349,15 @@ typedef struct goicp_shard_stats {
 	int32_t failed_rank;  /* -1, or the rank whose failure ended the run */
 } goicp_shard_stats;
 typedef struct goicp_shard_options {
-	int32_t rot_pops_per_step;  /* rotation parents per step (>= 1) */
+	int32_t rot_pops_per_step;  /* rotation parents per step (>= 1); with ramp_to: of the FIRST step */
 	int32_t rebalance;          /* 1: idle ranks receive cubes from the largest queue */
 	int32_t stale_exchange;     /* 0: the exchange of a step is consumed before the next step (bulk-synchronous);
 	                               1: it runs on a helper thread while the next step is evaluated and is consumed after it --
 	                               a rank waits only for ranks more than one step behind */
-	int32_t reserved;
+	int32_t ramp_to;            /* 0: every step expands rot_pops_per_step parents.  R > rot_pops_per_step: the step width doubles
+	                               from step to step up to R -- the single-GPU driver's own ramp (8, 16, 32, 64 rotation parents per
+	                               batch: few, large launches once a registration has proved to be long), one exchange per batch.
+	                               (This field was `reserved`, always 0, up to ABI 3.) */
 } goicp_shard_options;
 /* the engine side of the protocol as a callback table (goicp_register_sharded fills it for a real engine; tests
  * supply a CPU stand-in).  nodes7: 7 floats per rotation cube {corner x,y,z, width, ub, lb, level}. */
@@ -421,6 +427,15 @@ int goicp_debug_kabsch(const float H[9], float R[9]);
  */
 int goicp_debug_bounds_tile(goicp_handle h, const float* rots9, const float* parents4, int32_t nseg, int32_t n, int32_t level, int32_t chunks,
                             float* ub_tile, float* lb_tile, float* ub_direct, float* lb_direct, float ms[2], uint32_t stats[2]);
+/*
+ * goicp_debug_queue_expand (test): the n (<= 128) given translation nodes expanded by ONE round of the device-resident inner-BnB queues --
+ * an upper-bound search (maxRotDisL == NULL, jly_goicp.cpp:492) and a lower-bound search (rotation level `level`, :551) of the same
+ * rotation, both listing all n nodes: the lock-step round the outer search runs (bnb_queue_kernel selection + bounds_queue_kernel, the
+ * twin-fused evaluation when the engine has it on).  Outputs: the 8 children's (ub, lb) of every node for both passes, in the order of
+ * parents4 (inner body of GoICP::InnerBnB, jly_goicp.cpp:262-335).  info[0] = point chunks of the evaluation, info[1] = twin lists in use.
+ */
+int goicp_debug_queue_expand(goicp_handle h, const float R[9], int32_t level, const float* parents4, int32_t n, float* ub_ubpass, float* lb_ubpass,
+                             float* ub_lbpass, float* lb_lbpass, int32_t info[2]);
 /* diagnostics of the ICP pass's neighbour cache: two scoring passes at (R, t); *hits = queries of the second pass that
  * skipped the tree walk (-1 when the cache is off) */
 int goicp_debug_cache_hits(goicp_handle h, const float R[9], const float t[3], int64_t* hits);

@@ -12,6 +12,16 @@ from conftest import cloud, golden, load_pkg, rot_angle
 
 pytestmark = pytest.mark.gpu
 
+# Pose bar of every test below that compares with the reference's optimum outside _e2e (sharded, device- vs host-queue, flow, search-range
+# and fp16 runs; it was 3e-2 rad / 1e-2 up to round 3).  Measured on MI355X (round 4, printed by _pose_close): 5.1e-6 rad / 5.8e-7 for
+# every visit order that ends in the reference's ICP optimum, 4.3e-4 / 7.8e-5 for the boxed search -- so the bar is the strict mode's
+# 2e-3 / 2e-3.  Three orders (flow = 4, flow = 16 without adaptive_k, RCCL world 1 at 8 parents per step) end in a NEIGHBOURING ICP optimum
+# of the same basin, 2.075e-2 rad / 4.99e-3 away, whose SSE is LOWER than the reference's: Go-ICP guarantees the error, not the pose, and
+# the early exit (jly_goicp.cpp:527) takes the first optimum below SSEThresh.  That one deviation is accepted only when the run's SSE beats
+# the reference's, and held to the measured distance + 20 %.
+POSE_TOL = (2e-3, 2e-3)
+POSE_TOL_BETTER_OPTIMUM = (2.5e-2, 6e-3)
+
 
 @pytest.fixture(scope="module")
 def pkg():
@@ -428,6 +438,18 @@ def _e2e(pkg, tag, model, data, strict=True, wide_tol=(2e-3, 2e-3), **params):
     return eng, g
 
 
+
+def _pose_close(tag, R, t, g, tol=(2e-3, 2e-3), sse=None):
+    """Pose against the reference's optimum (golden e2e file g), printed so that the tolerance can be held to what is measured.
+    sse given: a pose outside `tol` is accepted when the run's SSE is strictly below the reference's (a better optimum than the
+    reference found) and the pose lies within POSE_TOL_BETTER_OPTIMUM."""
+    ang, dt = rot_angle(R, np.array(g["R"])), float(np.linalg.norm(np.asarray(t, np.float64).reshape(3) - np.array(g["t"])))
+    print("pose %s: rot_error_rad %.3e trans_error %.3e sse %s (reference %.6g; tolerance %.1e / %.1e)" % (tag, ang, dt, "%.6g" % sse if sse is not None else "-", g["sse"], tol[0], tol[1]))
+    if ang <= tol[0] and dt <= tol[1]:
+        return
+    assert sse is not None and sse < g["sse"] and ang <= POSE_TOL_BETTER_OPTIMUM[0] and dt <= POSE_TOL_BETTER_OPTIMUM[1], (tag, ang, dt, sse)
+
+
 def test_e2e_rand100_reference_order(pkg):
     eng, g = _e2e(pkg, "rand100", cloud("model_rand"), cloud("data_rand"), trans_batch=1, wide_children=0)
     c = eng.counters
@@ -532,6 +554,21 @@ def test_e2e_spanner_sub_wide(pkg):
         e.registration.close()
 
 
+def test_e2e_spanner_sparse_reference_order(pkg):
+    """BASELINE configs[3] with a NON-ZERO reference SSE (tests/golden/e2e_spanner_sparse.json: every 8th target point, every 50th
+    source point, mse 3e-4; the reference's Register: SSE 0.10996, 50 rotation / 3 150 translation nodes): the 2 % SSE bar that
+    e2e_spanner_sub (SSE exactly 0) cannot exercise.  Reference visit order: pose <= 2e-3 rad / 2e-3, SSE 2 %, node counts 2 %."""
+    eng, g = _e2e(pkg, "spanner_sparse", np.ascontiguousarray(cloud("spanner_target")[::8]), cloud("spanner_source", 50), trans_batch=1, wide_children=0)
+    assert g["sse"] > 0.05 and abs(eng.get_best_error() - g["sse"]) <= 0.02 * g["sse"]          # no absolute slack here
+    _e2e_counts(eng, g)
+    eng.registration.close()
+
+
+def test_e2e_spanner_sparse_wide(pkg):
+    eng, g = _e2e(pkg, "spanner_sparse", np.ascontiguousarray(cloud("spanner_target")[::8]), cloud("spanner_source", 50), strict=False)
+    eng.registration.close()
+
+
 def test_golden_inner_bnb_spanner(pkg):
     """The reference's InnerBnB on the spanner DT (tests/golden/inner_bnb_spanner.json): single expansions rel 1e-4 +
     arg-min child, full searches in the reference visit order value rel 1e-3, pops within 1 %."""
@@ -571,7 +608,7 @@ def test_sharded_two_ranks_same_optimum(pkg, bunny_model, bunny_data10):
         sse = [float(e.get_best_error()) for e in engines]
         assert sse[0] == sse[1] and all(s["status"] == 0 for s in stats)
         for e in engines:
-            assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2 and np.linalg.norm(e.optT - np.array(g["t"])) <= 1e-2
+            _pose_close("sharded2 stale=%d" % stale, e.optR, e.optT, g, POSE_TOL, sse=sse[0])
             assert sse[0] <= 1.02 * g["sse"] and sse[0] < g["sse_threshold"]
             e.registration.close()
 
@@ -1084,7 +1121,8 @@ def test_search_ranges_applied(pkg, bunny_model, bunny_data10):
     box = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], use_rot_range=1, rot_min=list(rv - 25), rot_max=list(rv + 20),
                         use_trans_range=1, trans_min=list(t0 - 0.2), trans_max=list(t0 + 0.25))
     box.run()
-    assert box.get_best_error() <= 1.02 * g["sse"] and rot_angle(box.optR, np.array(g["R"])) <= 3e-2
+    assert box.get_best_error() <= 1.02 * g["sse"]
+    _pose_close("search box", box.optR, box.optT, g, POSE_TOL)
     assert 0 < box.counters.rot_pops <= base.counters.rot_pops
     away = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], use_rot_range=1,
                          rot_min=list(-rv - 15), rot_max=list(-rv + 15), icp_max_iter=0, rot_search_depth=4, trans_search_depth=6)   # depth caps bound the run: without the optimum in reach the gap never closes
@@ -1135,7 +1173,7 @@ def test_flow_with_a_wide_rotation_batch(pkg, bunny_model, bunny_data10):
     eng = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], flow=8, rot_batch=256)
     eng.run()
     assert eng.finished and eng.get_best_error() <= 1.02 * g["sse"] and eng.get_best_error() < g["sse_threshold"]
-    assert rot_angle(eng.optR, np.array(g["R"])) <= 3e-2
+    _pose_close("flow rot_batch 256", eng.optR, eng.optT, g, POSE_TOL, sse=float(eng.get_best_error()))
     eng.registration.close()
 
 
@@ -1194,7 +1232,7 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
     ge = golden("e2e_bunny10")
     for e in (a, b):
         assert e.get_best_error() <= 1.02 * ge["sse"] and e.get_best_error() < ge["sse_threshold"]
-        assert rot_angle(e.optR, np.array(ge["R"])) <= 3e-2
+        _pose_close("device/host queues", e.optR, e.optT, ge, POSE_TOL)
     assert a.counters.bounds_launches > 0 and a.counters.queue_fallbacks == 0
     # the overflow path: with room for only 48 nodes per queue every long search outgrows its slab, the batch is flagged
     # and re-run through the host queues -- same values as the host driver, and the fallback is counted
@@ -1257,7 +1295,7 @@ def test_queue_round_width_and_continuous_flow(pkg, bunny_model, bunny_data10):
         e = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, **kw)
         e.run()
         assert e.get_best_error() <= 1.02 * ge["sse"] and e.get_best_error() < ge["sse_threshold"], kw
-        assert rot_angle(e.optR, np.array(ge["R"])) <= 3e-2, kw
+        _pose_close("flow %r" % (kw,), e.optR, e.optT, ge, POSE_TOL, sse=float(e.get_best_error()))
         assert e.counters.bounds_launches > 0
         if "queue_cap" in kw:
             assert e.counters.queue_fallbacks >= 1
@@ -1294,7 +1332,7 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
     assert st["exchanges"] >= 1 and st["broadcasts"] >= 1 and eng.finished
     assert st["status"] == 0 and st["failed_rank"] == -1 and st["wait_ms"] >= 0 and st["step_ms"] > 0
     assert eng.get_best_error() <= 1.02 * g["sse"] and eng.get_best_error() < g["sse_threshold"]
-    assert rot_angle(eng.optR, np.array(g["R"])) <= 3e-2
+    _pose_close("rccl world 1", eng.optR, eng.optT, g, POSE_TOL, sse=float(eng.get_best_error()))
     B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
     eng.registration.close()
     # the single-process multi-GPU driver behind `goicp_cli --ranks N` (ncclCommInitAll + one host thread per GPU), N = 1 here
@@ -1327,7 +1365,8 @@ def test_sharded_library_protocol_gpu(pkg, bunny_model, bunny_data10):
         best = [float(e.get_best_error()) for e in engines]
         assert max(best) == min(best)
         assert best[0] <= 1.02 * g["sse"] and best[0] < g["sse_threshold"]
-        assert all(rot_angle(e.optR, np.array(g["R"])) <= 3e-2 for e in engines)
+        for e in engines:
+            _pose_close("thread ranks world %d" % world, e.optR, e.optT, g, POSE_TOL, sse=best[0])
         assert len({(s["exchanges"], s["broadcasts"], s["donations"]) for s in stats}) == 1
         for r in range(world):
             lib.goicp_thread_comm_destroy(comms[r])
@@ -1459,6 +1498,177 @@ def test_compact_selection_of_proving_searches(pkg, bunny_model, bunny_data10):
     assert runs[256][3] != cubes0                                  # the order really changed
 
 
+
+# ----------------------------------------------------------------------------------------------
+# round 4: the lean sibling path, the queue round and the tile kernel against the oracle, all sixteen outputs
+# ----------------------------------------------------------------------------------------------
+def _expansion_parents(rng, n_per_depth, depths):
+    """Translation nodes (corner xyz + width) of the given depths inside the root cube [-0.5, 0.5]^3, as the BnB makes them:
+    corner = -0.5 + k * w with integer k (jly_goicp.cpp:262-273).  No node twice (a queue never holds one twice, and the twin test of
+    the evaluation matches nodes by value)."""
+    out = []
+    for d in depths:
+        w = np.float32(1.0) / np.float32(1 << d)
+        seen = set()
+        for kk in rng.integers(0, 1 << d, (4 * n_per_depth, 3)):
+            if tuple(kk) in seen or len(seen) >= min(n_per_depth, 8 ** d):
+                continue
+            seen.add(tuple(kk))
+            out.append([np.float32(-0.5) + np.float32(kk[0]) * w, np.float32(-0.5) + np.float32(kk[1]) * w, np.float32(-0.5) + np.float32(kk[2]) * w, w])
+    return np.array(out, np.float32)
+
+
+def _children(parent):
+    px, py, pz, pw = map(np.float32, parent)
+    w = pw / np.float32(2)
+    kids = []
+    for j in range(8):
+        cx = px + np.float32(j & 1) * w; cy = py + np.float32(j >> 1 & 1) * w; cz = pz + np.float32(j >> 2 & 1) * w
+        kids.append([cx + w / np.float32(2), cy + w / np.float32(2), cz + w / np.float32(2), w])
+    return np.array(kids, np.float32)
+
+
+def test_sibling_expansion_all_sixteen_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bunny_data):
+    """The path every registration and the headline bench run -- the LEAN sibling path (lean_points, device.hip; reference body
+    GoICP::InnerBnB, src/goicp/jly_goicp.cpp:262-335) -- on the FULL bunny (N = 30 379, V = 300: a grid that fits the Infinity Cache
+    selects it): for 43 parents of depths 0..6 (in-grid) plus 6 whose children straddle or leave the DT grid, under two rotations
+    and levels {-1, 5}, ALL sixteen outputs (8 ub and 8 lb of the children) against oracle.cube_bound, rel 1e-4 -- through
+      (i)   goicp_eval_bounds (bounds_kernel<1, true>, the microbench's kernel),
+      (ii)  one round of the device-resident queues with both passes listed (bnb_queue_kernel + bounds_queue_kernel<1, true> with
+            twin fusion: the lower-bound search's items evaluate both passes, lean_points<.., 2>),
+      (iii) the same round with twin fusion off (each search's own items),
+      (iv)  bounds_tile_kernel (LDS-staged DT boxes; its own lean path for boxes inside the grid, the gathering fall-back otherwise)."""
+    import ctypes as C
+    B = pkg.binding
+    rng = np.random.default_rng(11)
+    parents = _expansion_parents(rng, 7, range(0, 7))                   # 1 + 7 x 6 nodes
+    # nodes outside the root cube whose children straddle the grid's faces or lie beyond them (the grid is the target's bounding cube
+    # expanded twice: about [-1.75, 1.75]^3; the cloud reaches |p| = 1.4)
+    far = np.array([[0.75, -0.25, 0.0, 0.5], [-1.5, 0.5, 0.25, 0.5], [0.25, 1.0, -1.25, 0.25], [2.0, 2.0, -2.0, 1.0], [-0.5, -0.5, 0.875, 0.125],
+                    [1.0, -1.0, 1.0, 0.0625]], np.float32)
+    parents = np.concatenate([parents, far])
+    assert len(parents) >= 32
+    _, rho = oracle_mod.rot_radii(bunny_data)
+    regs = {tw: pkg.Registration(bunny_model, bunny_data, 1e-3, twin_fusion=tw) for tw in (1, 0)}
+    reg = regs[1]
+    lib, h = reg._lib, reg.handle
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    n = len(parents)
+    worst = {}
+    for v in ([0.3, -0.2, 0.9], [-2.1, 0.4, 1.1]):
+        R = pkg.fgoicp.rodrigues(v)
+        prot = oracle_mod.rotate(R, bunny_data)
+        level = 5
+        want = {}                                               # (pass, parent, child) -> (ub, lb) of the oracle
+        for ps, r in ((0, None), (1, rho[level])):
+            for e, par in enumerate(parents):
+                for c, kid in enumerate(_children(par)):
+                    want[(ps, e, c)] = oracle_mod.cube_bound(oracle_dt_bunny, prot, r, kid[:3], kid[3])
+
+        def check(tag, ps, ub, lb):
+            for e in range(n):
+                for c in range(8):
+                    ou, ol = want[(ps, e, c)]
+                    du, dl = abs(ub[8 * e + c] - ou) / max(ou, 1e-3), abs(lb[8 * e + c] - ol) / max(ol, 1e-3)
+                    worst[tag] = max(worst.get(tag, 0.0), du, dl)
+                    assert du <= 1e-4 and dl <= 1e-4, (tag, ps, e, c, ub[8 * e + c], ou, lb[8 * e + c], ol)
+                    assert lb[8 * e + c] <= ub[8 * e + c]
+        # (i) the operator API, eight siblings per group
+        kids = np.concatenate([_children(p) for p in parents])
+        for ps, lv in ((0, -1), (1, level)):
+            ub, lb = reg.eval_bounds(R, kids, lv)
+            check("eval_bounds", ps, ub, lb)
+        # (ii) / (iii) one round of the device queues, twin fusion on / off
+        for tw, r_ in regs.items():
+            out = [np.zeros(8 * n, np.float32) for _ in range(4)]
+            info = (C.c_int32 * 2)()
+            par = np.ascontiguousarray(parents.reshape(-1))
+            B.check(lib.goicp_debug_queue_expand(r_.handle, fp(np.ascontiguousarray(R.reshape(-1).astype(np.float32))), level, fp(par), n,
+                                                 fp(out[0]), fp(out[1]), fp(out[2]), fp(out[3]), info))
+            assert info[1] == tw
+            check("queue twin=%d chunks=%d" % (tw, info[0]), 0, out[0], out[1])
+            check("queue twin=%d chunks=%d" % (tw, info[0]), 1, out[2], out[3])
+        # (iv) the tile kernel: one segment of n <= 64 expansions, at the lower-bound pass's level and without radii
+        for ps, lv in ((0, -1), (1, level)):
+            for s0 in range(0, n, 32):
+                seg = np.ascontiguousarray(parents[s0:s0 + 32])
+                m = len(seg)
+                out = [np.zeros(8 * m, np.float32) for _ in range(4)]
+                ms, st = (C.c_float * 2)(), (C.c_uint32 * 2)()
+                B.check(lib.goicp_debug_bounds_tile(h, fp(np.ascontiguousarray(R.reshape(-1).astype(np.float32))), fp(seg.reshape(-1)), 1, m, lv, 4,
+                                                    fp(out[0]), fp(out[1]), fp(out[2]), fp(out[3]), ms, st))
+                for e in range(m):
+                    for c in range(8):
+                        ou, ol = want[(ps, s0 + e, c)]
+                        for tag, ub, lb in (("tile", out[0], out[1]), ("direct(parents)", out[2], out[3])):
+                            du, dl = abs(ub[8 * e + c] - ou) / max(ou, 1e-3), abs(lb[8 * e + c] - ol) / max(ol, 1e-3)
+                            worst[tag] = max(worst.get(tag, 0.0), du, dl)
+                            assert du <= 1e-4 and dl <= 1e-4, (tag, ps, s0 + e, c)
+    print("sixteen outputs vs oracle, worst relative deviation:", {k: "%.2e" % v for k, v in worst.items()})
+    for r_ in regs.values():
+        r_.close()
+
+
+def test_search_range_bound_on_a_split_plane(pkg):
+    """The cull of a configured search range (in_box, engine.hpp / bnbqueue.hip; the [params.translation] keys of the reference's
+    configs, src/common.h:157-169) takes a cube as the half-open box [x, x + w)^3 against the CLOSED range: the range's high face
+    is inclusive.  A z range of a quarter of the root's width puts BOTH its bounds on depth-3 split planes (root [c - w/2, c + w/2],
+    range [c - w/8, c + w/8]): of the four depth-3 layers around it the layer that starts at hi is kept, the layer that ends at lo is
+    not -- three layers of 64 cubes, not two (the strict form), not four.  A problem whose lower bounds are all 0 down to depth 3 and
+    whose upper bounds are never 0 makes the search expand every node in range down to the depth limit, so the pops COUNT the cull:
+    1 + 8 + 32 + 192 expansions at depth limit 4.  (Target: a lattice of spacing 0.02 -- no point of space is farther than 0.0173 from
+    it, below the 0.054 a depth-3 cube subtracts, so every lower bound is 0; five source points at incommensurate offsets -- no
+    cube centre puts all five into seeded voxels, so the incumbent stays above the lower bounds and above SSEThresh.)"""
+    ax = np.arange(-0.5, 0.8001, 0.02)
+    target = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    source = np.array([[0.0, 0.0, 0.0], [0.3037, 0.0011, 0.0023], [0.0041, 0.2513, 0.0079], [0.1517, 0.1009, 0.2031], [0.2203, 0.0307, 0.1129]], np.float32)
+    w = 0.5
+    lo, hi = [-w / 2, -w / 2, -w / 8], [w / 2, w / 2, w / 8]
+    for dq, tb in ((1, 32), (0, 32), (0, 1)):
+        reg = pkg.Registration(target, source, 1e-9, device_queues=dq, trans_batch=tb, wide_children=1 if tb > 1 else 0,
+                               use_trans_range=1, trans_min=lo, trans_max=hi, trans_search_depth=4)
+        v, best, cnt = reg.inner_bnb(np.eye(3, dtype=np.float32), -1, 1e10)
+        assert v > 5 * 1e-9                                                       # the incumbent stayed above the lower bounds (0) and above SSEThresh
+        assert cnt.trans_pops == 1 + 8 + 32 + 192, (dq, tb, cnt.trans_pops)
+        reg.close()
+
+
+def test_flow_with_trimming(pkg, bunny_model, bunny_data10):
+    """Continuous flow + trimming: the queue kernel widens a stale search's step up to x4, and the trimmed evaluation runs
+    one workgroup per listed expansion -- its grid must cover what the round can list (it was sized for q_hi x K: expansions listed
+    beyond that kept stale bounds).  Against the oracle's trimmed registration of the same clouds (tests/golden/e2e_bunny10_trim_oracle.json)
+    and the host-queue run: the flow run must reach the oracle's optimum (measured: SSE 0.35515 against 0.35528, pose 2e-4 rad away); the
+    widened host-queue run ends in a neighbouring optimum 1.7 % higher (0.045 rad away) -- held to the SSE bar only."""
+    o = golden("e2e_bunny10_trim_oracle")
+    kw = dict(trim_fraction=0.1)
+    a = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, flow=8, **kw)
+    b = pkg.FastGoICP(bunny_model, bunny_data10, 1e-3, device_queues=0, **kw)
+    a.run(); b.run()
+    assert a.finished and b.finished
+    for e in (a, b):
+        assert e.get_best_error() < e.sse_threshold and e.get_best_error() <= 1.02 * o["sse"]
+    print("flow + trim: sse %.6g, host queues %.6g, oracle %.6g; flow vs host queues rot %.3e" % (a.get_best_error(), b.get_best_error(), o["sse"], rot_angle(a.optR, b.optR)))
+    _pose_close("flow + trim vs the oracle's trimmed optimum", a.optR, a.optT, o, POSE_TOL, sse=float(a.get_best_error()))
+    a.registration.close(); b.registration.close()
+
+
+def test_tile_list_with_few_search_slots(pkg, bunny_model, bunny_data10):
+    """The tile list's segment buffer: with rot_batch = 1 the queues are sized for 16 search slots, and a few deep searches
+    widened to 100+ expansions each need more <= 64-expansion segments than 2 x slots.  The buffer holds list_cap / 64 + slots
+    segments now and the kernel checks it; a prove-the-optimum search with the tile list always on must agree with tiles off."""
+    res = {}
+    for tiles in (1, 0):
+        e = pkg.FastGoICP(bunny_model, bunny_data10, 1e-4, rot_batch=1, lds_tiles=tiles)
+        e.run()
+        assert e.finished
+        res[tiles] = (float(e.get_best_error()), e.counters.cubes, e.counters.tile_expansions, e.counters.queue_fallbacks, np.array(e.optR), np.array(e.optT))
+        e.registration.close()
+    assert res[1][2] > 0 and res[0][2] == 0                              # the tile list really ran
+    assert abs(res[1][0] - res[0][0]) <= 1e-4 * res[0][0]
+    assert abs(res[1][1] - res[0][1]) <= 0.02 * res[0][1]                  # same search (last-bit differences of the sums only)
+    assert rot_angle(res[1][4], res[0][4]) <= 1e-4
+
+
 def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     """Params::bounds_fp16 (opt-in, not the parity path): the BnB bounds read a half-precision copy of the bricked DT
     rounded toward zero.  Against the fp32 engine on the same cubes: every lower bound is <= the fp32 one (still a valid
@@ -1482,7 +1692,7 @@ def test_bounds_fp16_optin(pkg, bunny_model, bunny_data10):
     e = pkg.FastGoICP(bunny_model, bunny_data10, g["mse_threshold"], bounds_fp16=1)
     e.run()
     assert e.get_best_error() <= 1.02 * g["sse"] and e.get_best_error() < g["sse_threshold"]
-    assert rot_angle(e.optR, np.array(g["R"])) <= 3e-2
+    _pose_close("bounds_fp16", e.optR, e.optT, g, POSE_TOL)
     e.registration.close()
 
 

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(pkg):
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in the header but not exported" % name
     assert declared == set(binding.SYMBOLS), (declared ^ set(binding.SYMBOLS))
-    assert lib.goicp_abi_version() == 3
+    assert lib.goicp_abi_version() == 4
 
 
 def test_struct_sizes_match_abi(pkg):

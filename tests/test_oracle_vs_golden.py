@@ -196,6 +196,16 @@ def test_e2e_spanner_sub(oracle_mod):
     _check_e2e_sub(oracle_mod, "spanner_sub", cloud("spanner_target"), cloud("spanner_source", 50))
 
 
+def test_e2e_spanner_sparse(oracle_mod):
+    """BASELINE configs[3] with an SSE bar that bites: every 8th point of the noisy spanner as the target (18 750 points), every
+    50th point of the rotated model, mse 3e-4.  spanner_sub's optimum scores SSE exactly 0 (so do strides 37 and 10 of the source:
+    the dense noisy target seeds every voxel near the surface); here the reference's initial ICP stops in a local minimum (1.53),
+    its search finds the optimum at SSE 0.10996 after 50 rotation / 3 150 translation nodes and takes the early exit."""
+    g = golden("e2e_spanner_sparse")
+    assert g["sse"] > 0.05                      # the point of this fixture
+    _check_e2e_sub(oracle_mod, "spanner_sparse", np.ascontiguousarray(cloud("spanner_target")[::8]), cloud("spanner_source", 50))
+
+
 def test_inner_bnb_spanner(oracle_mod):
     """The reference's InnerBnB on the spanner DT (V = 300 over the 150 000 noisy target points), every 50th source
     point: single expansions (min ub + arg-min child) and full searches, as test_inner_bnb_* do on the bunny."""

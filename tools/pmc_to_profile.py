@@ -56,4 +56,13 @@ else:
                 res["pass_per_wave"] = {c: (e.get(c) or 0.0) / w for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")}
     res["hbm_bytes_per_pass_corrected"] = tot_corr
     res["l2_miss_bytes_per_pass_128B_lines"] = tot_miss
+# provenance: the kernels these counters were collected on.  kernel_source_hash = what the loaded library reports (csrc/Makefile: sha256 over
+# the kernel sources); git_head = GOICP_GIT_HEAD of the collecting command (the GPU box has no .git; tools/profile_round.sh passes it on).
+# bench.py quotes `traffic` from a profile only when its hash equals the library's.
+sys.path.insert(0, os.path.dirname(here))
+from __graft_entry__ import _pkg  # noqa: E402
+_p = _pkg()
+res["kernel_source_hash"] = _p.load_library().goicp_kernel_source_hash().decode()
+res["kernel_source_hash_of_tree"] = _p.kernel_source_hash()
+res["git_head"] = os.environ.get("GOICP_GIT_HEAD", "unknown")
 print(json.dumps(res, indent=1))

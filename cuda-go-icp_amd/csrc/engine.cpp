@@ -146,7 +146,12 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	if (p_.device >= ndev) throw std::invalid_argument("goicp: device ordinal out of range");
 	if (p_.device >= 0) dev_ = p_.device; else HIPCHK(hipGetDevice(&dev_));
 	DeviceGuard guard(dev_);
-	HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+	if (p_.stream_priority > 0) {
+		int least = 0, greatest = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
+	} else
+		HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate(&ev0_));
 	HIPCHK(hipEventCreate(&ev1_));
 
@@ -468,6 +473,16 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 		std::memcpy(rot[0].r, I9, sizeof(I9));
 		run_inner_device(one, rot);
+		{
+			// ... and the read-back of a batch's search records at the sizes a registration uses (tens of KB): measured on MI355X, the FIRST
+			// device-to-host copy of such a size after kernels have run costs 8.6 ms (a one-time set-up inside the runtime; the 80-byte
+			// read-back of the dummy search above does not trigger it, neither does the copy made before any kernel ran) -- it belongs to
+			// engine creation, not to the first registration (full bunny: first run 43 -> 34 ms)
+			const double tw = now_ms();
+			for (size_t n = 1; n <= cap_qsearch_; n *= 2) HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * n, hipMemcpyDeviceToHost, stream_));
+			HIPCHK(hipStreamSynchronize(stream_));
+			if (p_.verbose) std::fprintf(stderr, "[goicp] create: read-back warm-up %.2f ms\n", now_ms() - tw);
+		}
 		if (flow_mode()) {
 			// the same for the continuous-flow driver: its list-init kernel, the full-size rotation table upload and the
 			// full-size read-back of the search records, once, here
@@ -494,6 +509,19 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		queue_rounds_ = 0;
 	}
 
+	{
+		// the first launch of the ICP kernels, of the scoring launch and their first state / result read-backs also belong to engine creation
+		// (measured: the first registration's ICP stretch 18.3 ms against 13.2 ms for every later one)
+		const double tw = now_ms();
+		const float I0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z0[3] = {0, 0, 0};
+		float Rw[9], tw3[3];
+		std::memcpy(Rw, I0, sizeof(I0)); std::memcpy(tw3, Z0, sizeof(Z0));
+		int itw = 0;
+		icp_run(Rw, tw3, 2 * std::max(1, p_.icp_chunk) + 1, -1e30f, &itw);       // three chunks: both fetch slots and both events are used once
+		(void)eval_sse(I0, Z0);
+		cnt_ = Counters{};
+		if (p_.verbose) std::fprintf(stderr, "[goicp] create: ICP + scoring warm-up %.2f ms\n", now_ms() - tw);
+	}
 	const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	std::memcpy(optR_, I, sizeof(I)); std::memcpy(curR_, I, sizeof(I)); std::memcpy(stepR_, I, sizeof(I));
 	std::memset(optT_, 0, sizeof(optT_)); std::memset(curT_, 0, sizeof(curT_)); std::memset(stepT_, 0, sizeof(stepT_));
@@ -1130,7 +1158,10 @@ void Engine::ensure_queues(size_t nsearch)
 		HIPCHK(hipMalloc(&qsort_.order, sizeof(unsigned) * max_groups * sort_chunks));
 		HIPCHK(hipMalloc(&qsort_.hist, qsort_hist_bytes()));
 		HIPCHK(hipMemsetAsync(qsort_.hist, 0, qsort_hist_bytes(), stream_));     // kept zero between uses by the kernels themselves
-		qsort_.chunk_pts = kSortChunkPts; qsort_.chunks = sort_chunks; qsort_.min_groups = 2048;                    // rounds from this many expansions: 512 35.0 | 1024 34.5 | 2048 33.6 | 4096 37.3 ms
+		qsort_.chunk_pts = kSortChunkPts; qsort_.chunks = sort_chunks; qsort_.min_groups = 256;
+		if (const char* e = std::getenv("GOICP_SORT_MIN_GROUPS")) { const int v = std::atoi(e); if (v > 0) qsort_.min_groups = v; }     // tuning only (tools/tune_e2e.py); the default is the measured optimum                    // rounds from this many expansions.  Round 3 (512 | 1024 | 2048 | 4096): 35.0 | 34.5 | 33.6 | 37.3 ms.  Re-swept in round 4 with the
+		// twin lists and the 4 096-point chunks in place (tools/sort_threshold_probe.py, median of 7): 1 | 128 | 512 | 1024 | 2048 | 4096 | off = 33.8 | 33.3 | 33.5 | 33.6 | 34.4 | 36.6 | 36.3 ms;
+		// mse 1e-4 / 3e-5 (0.27 / 6.8 s) flat between 128, 256 and 2048 -- so round 1 of a large batch (230 roots x two passes) is sorted too
 		qsort_.shift = qsort_shift(dt_.V);           // 16-voxel cells (32-voxel cells: 35.1 ms)
 	}
 	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups, qsort_.order ? qsort_.chunks : 0)));
@@ -1243,6 +1274,8 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	const double t2 = now_ms();
 	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
+	if (p_.verbose > 1 && now_ms() - t2 > 1.0) std::fprintf(stderr, "[goicp] slow read-back of %zu search records: %.2f ms\n", S, now_ms() - t2);
+	const double t3 = now_ms();
 	for (size_t i = 0; i < S; i++) {
 		const QSearch& q = h_qsearch_[i];
 		InnerSearch& s = *searches[i];
@@ -1250,6 +1283,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
 		s.pops = q.pops; s.cubes = q.cubes; s.min_ub = q.min_ub;
 	}
+	if (p_.verbose > 1 && now_ms() - t3 > 1.0) std::fprintf(stderr, "[goicp] slow digest of %zu search records: %.2f ms\n", S, now_ms() - t3);
 	t_collect_ += now_ms() - t2;
 	return true;
 }

@@ -53,6 +53,7 @@ struct Params {
 	int stale_compact = 2048;     // a proving inner search whose queue holds at least this many nodes selects by Morton order of the cubes' corners instead of by lower
 	                              // bound (spatially compact, depth-first-like: LDS-tile material, and the slab stops overflowing); 0: always by lower bound
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
+	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
 	// Search domain ([params.rotation] / [params.translation] of the reference's configs, test/skull_goicp.toml:22-41;

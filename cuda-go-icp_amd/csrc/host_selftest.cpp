@@ -33,6 +33,7 @@ struct ToyEngine {
 	float best = 1e9f, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
 	int rank = 0, world = 1;
 	long long pops = 0;
+	std::vector<int> widths;                             // max_pops of every step (the protocol's step rule)
 	static float value(int id) { return 10.f + (float)((unsigned)(id * 2654435761u) >> 20) * 1e-3f; }
 	static float bound(int id, int depth) { return value(id) - 8.f / (float)(1 + depth); }
 	void begin(int r, int w)
@@ -43,6 +44,7 @@ struct ToyEngine {
 	}
 	void step(int max_pops, goicp_step_status* s)
 	{
+		widths.push_back(max_pops);
 		int n = 0;
 		while (!q.empty() && n < max_pops) {
 			Cube c = q.top(); q.pop(); n++; pops++;
@@ -115,7 +117,7 @@ goicp_shard_engine_ops toy_ops(ToyEngine* e)
 	return eo;
 }
 
-float run_world(int world, int rebalance, long long* donations, int stale = 0)
+float run_world(int world, int rebalance, long long* donations, int stale = 0, int ramp_to = 0)
 {
 	std::vector<ToyEngine> eng((size_t)world);
 	std::vector<goicp_comm_ops> comm((size_t)world);
@@ -125,11 +127,15 @@ float run_world(int world, int rebalance, long long* donations, int stale = 0)
 	for (int r = 0; r < world; r++)
 		th.emplace_back([&, r] {
 			goicp_shard_engine_ops eo = toy_ops(&eng[(size_t)r]);
-			goicp_shard_options o{3, rebalance, stale, 0};
+			goicp_shard_options o{3, rebalance, stale, ramp_to};
 			CHECK(goicp::run_sharded(&eo, &comm[(size_t)r], &o, &st[(size_t)r]) == GOICP_OK);
 		});
 	for (auto& t : th) t.join();
 	for (int r = 0; r < world; r++) {
+		// the step rule: a fixed width, or doubling from the first step's width up to ramp_to -- the same sequence on every rank
+		const std::vector<int>& w = eng[(size_t)r].widths;
+		CHECK(!w.empty() && w == eng[0].widths);
+		for (size_t i = 0; i < w.size(); i++) CHECK(w[i] == (ramp_to > 3 ? std::min(ramp_to, 3 << std::min<size_t>(i, 20)) : 3));
 		CHECK(eng[(size_t)r].best == eng[0].best);
 		CHECK(st[(size_t)r].exchanges == st[0].exchanges && st[(size_t)r].broadcasts == st[0].broadcasts);
 		CHECK(st[(size_t)r].failed_rank == -1 && st[(size_t)r].wait_ms >= 0.0);
@@ -210,6 +216,15 @@ int main()
 	// one-step-stale exchange (helper thread): same optimum, collectives still matched on every rank
 	for (int w : {2, 4, 7}) CHECK(std::fabs(run_world(w, 1, &don, 1) - single) <= 0.01f);
 	CHECK(std::fabs(run_world(3, 0, &don, 1) - single) <= 0.01f && don == 0);
+	// the step ramp (goicp_shard_options.ramp_to): widths 3, 6, 12, 24, 24 ... on every rank, same optimum; with the stale exchange too
+	for (int w : {1, 2, 4, 7}) CHECK(std::fabs(run_world(w, 1, &don, 0, 24) - single) <= 0.01f);
+	CHECK(std::fabs(run_world(4, 1, &don, 1, 24) - single) <= 0.01f);
+	{   // a caller's own communicator is not one of the library's: its ctx is never dereferenced
+		goicp_comm_ops own{};
+		own.ctx = reinterpret_cast<void*>(0x1); own.world = 1;
+		own.allreduce_min_u64 = [](void*, uint64_t*, size_t) { return 0; };
+		CHECK(goicp::comm_set_timeout_ms(&own, 100) == GOICP_ERR_INVALID);
+	}
 	// failure is a collective decision; a lost rank is a timeout
 	for (int stale : {0, 1}) {
 		run_failure(2, 1, 1, 3, stale);      // step fails on rank 1 at its 3rd step

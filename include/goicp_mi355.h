@@ -176,6 +176,8 @@ typedef struct goicp_params {
 	                          * (jly_goicp.cpp:257) has to be expanded whatever the order, a run of Morton-neighbours is spatially compact (LDS-tile
 	                          * material) and is explored depth-first-like, so the queue slab stops overflowing into the host fall-back.  0: always
 	                          * by lower bound (the reference's order, jly_goicp.h:64-71) */
+	int32_t stream_priority; /* 0 (default): the engine's HIP stream has the default priority; 1: the highest the device offers (hipStreamCreateWithPriority)
+	                          * -- for a latency-bound engine (an ICP loop) that shares the GPU with a throughput engine; measured: tools/overlap_probe.py */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);
@@ -379,7 +381,7 @@ int goicp_run_sharded(const goicp_shard_engine_ops* engine, const goicp_comm_ops
 int goicp_register_sharded(goicp_handle h, const goicp_comm_ops* comm, int32_t rot_pops_per_step, int32_t rebalance,
                            goicp_shard_stats* stats);
 /* both with the full option set */
-void goicp_shard_options_default(goicp_shard_options* out);
+void goicp_shard_options_default(goicp_shard_options* out);   /* 8 parents in the first step, ramp_to 32, rebalancing on, bulk-synchronous */
 int goicp_run_sharded_opt(const goicp_shard_engine_ops* engine, const goicp_comm_ops* comm, const goicp_shard_options* opt,
                           goicp_shard_stats* stats);
 int goicp_register_sharded_opt(goicp_handle h, const goicp_comm_ops* comm, const goicp_shard_options* opt, goicp_shard_stats* stats);

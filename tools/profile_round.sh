@@ -5,6 +5,7 @@ set -e
 r=$1; out=gpurun_out/prof_$r
 export TMPDIR=/tmp
 mkdir -p $out
+export GOICP_GIT_HEAD=${GOICP_GIT_HEAD:-unknown}
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${r}_bench.json 2> $out/bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${r}_bench_under_rocprof.json 2> $out/trace.err

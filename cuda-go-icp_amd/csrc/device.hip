@@ -2184,31 +2184,33 @@ __global__ __launch_bounds__(kFinThreads) void icp_finalize_update(const float* 
 	if (threadIdx.x < 64) finalize_rows(sh.sums, state, sh.st, (int)threadIdx.x);
 }
 
-// the finalize of the fixed-point form: 32 replicas x 16 accumulators in, zeroed again on the way out
-__global__ __launch_bounds__(kFinThreads) void icp_finalize_update_acc(unsigned long long* __restrict__ acc, IcpState* __restrict__ state)
+// the finalize of the fixed-point form: 32 replicas x 16 accumulators in, zeroed again on the way out.  ONE wavefront (round 4; it was a
+// workgroup of 1 024 threads, one accumulator each): lane t owns accumulator t & 15 of the replicas (t >> 4) + 4 j -- eight loads in flight,
+// two shuffles, no cross-wavefront stage -- and a single wavefront finds a free SIMD at once where sixteen had to wait for a whole compute
+// unit (tools/overlap_probe.py: beside a bound-evaluation stream the old form waited ~400 us per iteration).  Integer sums: the same totals.
+constexpr int kFinAccThreads = 64;
+__global__ __launch_bounds__(kFinAccThreads) void icp_finalize_update_acc(unsigned long long* __restrict__ acc, IcpState* __restrict__ state)
 {
-	__shared__ FinScratch sh;
-	__shared__ long long wtot[kIcpAccReplicas * kIcpAcc / 64][kIcpAcc];
-	static_assert(kIcpAccReplicas * kIcpAcc <= kFinThreads && (kIcpAccReplicas * kIcpAcc) % 64 == 0, "one accumulator per thread, whole wavefronts");
-	if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<unsigned*>(&sh.st)[threadIdx.x] = reinterpret_cast<const unsigned*>(state)[threadIdx.x];
-	if (state->converged) return;                 // uniform; the pass kernel added nothing
+	__shared__ double sums[kIcpAcc];
+	__shared__ IcpState st;
+	static_assert(sizeof(IcpState) / 4 <= kFinAccThreads && (kIcpAccReplicas * kIcpAcc) % kFinAccThreads == 0 && kFinAccThreads / kIcpAcc == 4, "one state word per lane; four replicas per pass of the wavefront");
 	const int t = threadIdx.x;
-	if (t < kIcpAccReplicas * kIcpAcc) {
-		long long x = (long long)acc[t];
-		acc[t] = 0ull;                            // the next pass starts from zero (it cannot start before this kernel has finished)
-		x += __shfl_xor(x, 16, 64);
-		x += __shfl_xor(x, 32, 64);
-		if ((t & 63) < kIcpAcc) wtot[t >> 6][t & 15] = x;
-	}
-	__syncthreads();
-	if (t < kIcpAcc) {
-		long long tot = 0;
+	if (t < (int)(sizeof(IcpState) / 4)) reinterpret_cast<unsigned*>(&st)[t] = reinterpret_cast<const unsigned*>(state)[t];
+	if (state->converged) return;                 // uniform; the pass kernel added nothing
+	long long v[kIcpAccReplicas * kIcpAcc / kFinAccThreads];
 #pragma unroll
-		for (int w = 0; w < kIcpAccReplicas * kIcpAcc / 64; w++) tot += wtot[w][t];
-		sh.sums[t] = (double)tot * (double)sh.st.acc_inv;
-	}
+	for (int j = 0; j < kIcpAccReplicas * kIcpAcc / kFinAccThreads; j++) v[j] = (long long)acc[kFinAccThreads * j + t];
+#pragma unroll
+	for (int j = 0; j < kIcpAccReplicas * kIcpAcc / kFinAccThreads; j++) acc[kFinAccThreads * j + t] = 0ull;   // the next pass starts from zero (it cannot start before this kernel has finished)
+	long long x = 0;
+#pragma unroll
+	for (int j = 0; j < kIcpAccReplicas * kIcpAcc / kFinAccThreads; j++) x += v[j];
+	x += __shfl_xor(x, 16, 64);
+	x += __shfl_xor(x, 32, 64);
+	__syncthreads();                              // the state words are in LDS
+	if (t < kIcpAcc) sums[t] = (double)x * (double)st.acc_inv;
 	__syncthreads();
-	if (t < 64) finalize_rows(sh.sums, state, sh.st, t);
+	finalize_rows(sums, state, st, t);
 }
 
 // test-only entry (goicp_debug_kabsch): the device SVD on a caller-supplied H, one lane
@@ -2389,7 +2391,7 @@ hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const Kd
 		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
 		else if (kd.K == 2) launch_pass_acc<2>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
 		else launch_pass_acc<3>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
-		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinThreads), 0, stream, acc, st);
+		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinAccThreads), 0, stream, acc, st);
 		return hipGetLastError();
 	}
 	if (ticket) {

@@ -1491,6 +1491,8 @@ void Engine::register_begin()
 	cancel_.store(false);
 	early_exit_ = converged_ = false;
 	rot_ramp_ = 8;
+	late_icp_.clear(); batches_done_ = 0;
+	{ const char* e = std::getenv("GOICP_ICP_DELAY_BATCHES"); icp_delay_ = e ? std::max(0, std::atoi(e)) : 0; }
 	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
 	std::memset(level_hist_, 0, sizeof(level_hist_));
 	cnt_ = Counters{};
@@ -1569,6 +1571,12 @@ bool Engine::handle_ub(Kid& k, const SearchOut& s)
 	float R[9], ti[3];
 	std::memcpy(R, k.R, sizeof(R)); std::memcpy(ti, t, sizeof(ti));
 	float e = icp_from(R, ti);
+	if (icp_delay_ > 0) {
+		LateIcp li; li.e = e; std::memcpy(li.R, R, sizeof(R)); std::memcpy(li.t, ti, sizeof(ti)); li.due = batches_done_ + icp_delay_;
+		late_icp_.push_back(li);
+		publish(false);
+		return false;
+	}
 	if (e < opt_err_) adopt(e, R, ti);
 	if (p_.verbose) std::fprintf(stderr, "[goicp] rank %d  error* %.6g (ub %.6g, level %d)\n", rank_, opt_err_, s.best, k.node.l);
 	publish(false);
@@ -1580,6 +1588,23 @@ bool Engine::handle_ub(Kid& k, const SearchOut& s)
 	}
 	queue_.swap(nq);
 	return false;
+}
+
+void Engine::fold_late_icp(bool all)
+{
+	for (size_t i = 0; i < late_icp_.size();) {
+		if (!all && late_icp_[i].due > batches_done_) { i++; continue; }
+		const LateIcp li = late_icp_[i];
+		late_icp_.erase(late_icp_.begin() + (long)i);
+		if (li.e < opt_err_) {
+			adopt(li.e, li.R, li.t);
+			if (opt_err_ < sse_thresh_) early_exit_ = true;
+			std::priority_queue<Node> nq;
+			while (!queue_.empty()) { Node n = queue_.top(); queue_.pop(); if (n.lb < opt_err_) nq.push(n); else break; }
+			queue_.swap(nq);
+			publish(false);
+		}
+	}
 }
 
 // :551-562: the lower-bound search is in
@@ -1824,7 +1849,11 @@ StepStatus Engine::register_step(int max_rot_pops)
 		bnb_ms_ -= icp_ms_ - icp0;           // flow_step's clock also ran through the ICP runs it triggered
 		publish(false);
 	} else
-	while (!early_exit_ && !converged_ && !cancel_.load() && !queue_.empty() && pops < max_rot_pops) {
+	while (true) {
+		if (!late_icp_.empty()) fold_late_icp(early_exit_ || converged_ || queue_.empty());      // nothing left to run beside: wait for every refinement
+		if (early_exit_ || cancel_.load() || pops >= max_rot_pops) break;
+		if (converged_ || queue_.empty()) { if (late_icp_.empty()) break; continue; }
+		batches_done_++;
 		// Rotation parents expanded together: ramps 8, 16, 32 ... rot_batch.  Easy registrations end in
 		// the first rounds and pay for little speculation; long searches run with few, large launches
 		// (full bunny: 310 launches / 63 ms at a fixed 8, 52 launches / 55 ms at 64).
@@ -1862,6 +1891,7 @@ StepStatus Engine::register_step(int max_rot_pops)
 		process_parents(parents);
 		publish(false);
 	}
+	if (!late_icp_.empty() && (early_exit_ || converged_ || queue_.empty())) fold_late_icp(true);
 	StepStatus st{};
 	st.early_exit = early_exit_ ? 1 : 0;
 	st.finished = (early_exit_ || converged_ || (queue_.empty() && flights_.empty()) || cancel_.load()) ? 1 : 0;

@@ -294,6 +294,13 @@ private:
 	float optR_[9], optT_[3], curR_[9], curT_[3];
 	bool early_exit_ = false, converged_ = false;
 	int rot_ramp_ = 8;
+	// experiment knob (env GOICP_ICP_DELAY_BATCHES = k, tools/icp_delay_probe.py): a refinement's result is folded in k rotation batches after
+	// the upper bound that triggered it -- what an ICP overlapped with the next batches would do to the search, without the concurrency
+	struct LateIcp { float e, R[9], t[3]; long long due; };
+	std::vector<LateIcp> late_icp_;
+	int icp_delay_ = 0;
+	long long batches_done_ = 0;
+	void fold_late_icp(bool all);
 	Counters cnt_;
 	std::atomic<bool> cancel_{false};
 	std::mutex mtx_;

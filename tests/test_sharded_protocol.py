@@ -185,3 +185,39 @@ def test_gloo_world2_rank_failure_exits_nonzero(fe_mod, tmp_path):
     assert res is not None, r.stderr[-3000:]
     assert res[1]["stats"]["status"] == -6 and res[0]["stats"]["status"] == -8
     assert res[0]["stats"]["failed_rank"] == 1 and res[1]["stats"]["failed_rank"] == 1
+
+
+def test_bench_plain_launch_propagates_a_failed_rank():
+    """`python3 bench.py --gpus 2` started plainly (no torchrun, no WORLD_SIZE -- the driver's command) makes the process the LAUNCHER: it
+    starts two fresh rank processes and never touches a GPU itself.  On this GPU-less container every rank ends with "bench.py needs a
+    GPU": the launcher must come back promptly with a non-zero exit code and no JSON line on stdout -- not hang, not report success."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the success path is test_bench_plain_launch_two_ranks_gloo (-m gpu)")
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 200
+
+
+@pytest.mark.gpu
+def test_bench_plain_launch_two_ranks_gloo():
+    """The N > 1 bench exactly as the driver starts it -- `python3 bench.py --gpus 2 ...`, no launcher around it -- rehearsed with two ranks
+    on this box's one GPU (gloo carries the exchanges; each rank still drives the HIP engine): exit code 0, ONE JSON line on stdout with
+    n_gpus 2, the sharded legs present and error-free, the deep leg reaching the world-1 optimum with its work inflation reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--prewarm", "2",
+                        "--sustain-s", "0", "--s2-steps", "0", "--no-cpu", "--no-probe", "--e2e-repeats", "1", "--deep-mse", "1e-4"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("{")]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["metric"] == "bnb_cube_bounds_per_s"
+    sh = j["e2e_sharded"]
+    assert "error" not in sh and "error" not in sh["spanner"] and sh["spanner"]["bulk_synchronous"]["sse"] < sh["spanner"]["bulk_synchronous"]["sse_threshold"]
+    d = sh["deep"]
+    assert d["same_optimum"] and d["world1"]["cube_bounds"] > 0 and 0.5 < d["work_inflation"] < 2.0 and d["speedup_vs_world1"] > 0

@@ -154,6 +154,10 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 	HIPCHK(hipEventCreate(&ev0_));
 	HIPCHK(hipEventCreate(&ev1_));
+	HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+	{ const char* e = std::getenv("GOICP_TILE_CONCURRENT"); if (e) tile_concurrent_ = std::atoi(e) != 0; }     // A/B only (tools/tile_deep.py)
 
 	h_target_.assign(target, target + 3 * M);
 	if (!(p_.trim_fraction >= 0.f) || p_.trim_fraction >= 1.f) throw std::invalid_argument("goicp: trim_fraction must be in [0,1)");
@@ -562,6 +566,10 @@ void Engine::release()
 	}
 	if (ev0_) hipEventDestroy(ev0_);
 	if (ev1_) hipEventDestroy(ev1_);
+	if (stream2_) { hipStreamSynchronize(stream2_); hipStreamDestroy(stream2_); }
+	if (ev_fork_) hipEventDestroy(ev_fork_);
+	if (ev_join_) hipEventDestroy(ev_join_);
+	stream2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
 	if (stream_) hipStreamDestroy(stream_);
 	d_src_ = nullptr; d_dt_ = nullptr; d_overshoot_ = nullptr; d_kd_pts_ = nullptr;
 	for (int l = 0; l < kMaxLevels; l++) d_kd_boxes_[l] = nullptr;
@@ -1234,13 +1242,26 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		for (int r = 0; r < chunk; r++) {
 			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr,
 			                        twins ? d_qpsearch_[parity] : nullptr));
+			// The round's two lists are independent (own records, own bounds, own partial sums), so the tile list's evaluation CAN be forked onto a
+			// second stream right behind the queue kernel and run beside the direct list's.  Built and measured (EXPERIMENTS R4.8): slower -- bunny
+			// mse 3e-5 6.73 -> 7.40 s, bunny/10 1.09 -> 1.14 s, identical results -- the VALU-bound tile kernel (32 KB of LDS per workgroup) and the
+			// gather kernel (122 VGPRs) take each other's occupancy; opt-in for A/B only
+			const bool fork_tiles = qp.tile_on && tile_concurrent_;
+			if (fork_tiles) {
+				HIPCHK(hipEventRecord(ev_fork_, stream_));
+				HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+				HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream2_));
+				HIPCHK(hipEventRecord(ev_join_, stream2_));
+				tile_rounds_++;
+			}
 			const bool sorted = sort_round && std::min<long long>(round_cap, max_groups) >= qsort_.min_groups;
 			if (sorted) HIPCHK(launch_queue_sort(d_qparents_[parity], d_rots_, &d_qctl_->n_groups[parity], max_groups, qsort_, bounds_dt(), stream_));
 			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
 			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, sorted ? &qsort_ : nullptr));
 			if (round_cap < (1ll << 40)) round_cap *= 8;
 			rounds_done++;
-			if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
+			if (fork_tiles) HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
+			else if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
 			last = parity;
 			parity ^= 1;
 			cnt_.bounds_launches++;

@@ -231,6 +231,11 @@ private:
 
 	hipStream_t stream_ = nullptr;
 	hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+	// A/B only (env GOICP_TILE_CONCURRENT = 1): the tile list's evaluation BESIDE the direct list's (two independent kernels of the same round) on a
+	// second stream, forked after the queue kernel and joined before the next one.  Measured slower (EXPERIMENTS R4.8): default off
+	hipStream_t stream2_ = nullptr;
+	hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+	int tile_concurrent_ = 0;
 	float4* d_src_ = nullptr;         // N  (x,y,z,|p|), k-d order (Params::morton_sort)
 	std::vector<int32_t> src_perm_;   // sorted position -> original index
 	std::vector<float> h_src_sorted_; // N*4

@@ -1155,9 +1155,14 @@ void Engine::ensure_queues(size_t nsearch)
 	// chunk 2 048 | 3 072 | 4 096 | 6 144 | search order: bunny 34.4 | 33.1 | 33.8 | 34.1 | 36.8 (run-to-run +-0.6); bunny mse 1e-4 280 | 277 | 280 | 276 | 295;
 	// synthetic 40 k mse 3e-5 798 | 758 | 714 | 725 | 921; spanner 150 k mse 2e-5 223 | 212 | 206 | 201 | 195 -- above ~64 k points the unsorted
 	// launch's large chunks win, so the feature stops there
-	constexpr int kSortChunkPts = 4096;
+	// round 4: the cloud is cut into TEN chunks (rounded up to 256 points) rather than into chunks of 4 096 points -- re-swept with the threshold at
+	// 256 expansions (tools/sort_threshold_probe.py chunks / chunks2, registration in ms): bunny (30 k) 2 048 | 2 560 | 3 072 | 4 096 points =
+	// 32.8 | 31.8-32.4 | 32.5 | 34.3, bunny mse 1e-4 271 | 266 | 267 | 270, synthetic 40 k at mse 3e-5 -- | 770 | 765 | 720 (3 584: 744), every second
+	// bunny point (15 k) 1 280 .. 4 096: 26.3-27.4, flat: ten chunks is 3 072 / 4 096 / 1 536 points there
+	int kSortChunkPts = (int)(((N_ + 9) / 10 + 255) / 256 * 256);
+	if (const char* e = std::getenv("GOICP_SORT_CHUNK_PTS")) { const int v = std::atoi(e); if (v >= 256) kSortChunkPts = v; }     // tuning only
 	const int sort_chunks = (int)((N_ + kSortChunkPts - 1) / kSortChunkPts);
-	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && sort_chunks >= 4 && sort_chunks <= 16) {
+	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && N_ >= 12288 && N_ <= 65536 && sort_chunks >= 4 && sort_chunks <= 16) {
 		float4* cen = nullptr;
 		HIPCHK(hipMalloc(&cen, sizeof(float4) * sort_chunks));
 		HIPCHK(launch_chunk_centroids(d_src_, (int)N_, kSortChunkPts, cen, stream_));

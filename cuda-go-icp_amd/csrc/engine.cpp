@@ -567,6 +567,7 @@ void Engine::release()
 	if (ev0_) hipEventDestroy(ev0_);
 	if (ev1_) hipEventDestroy(ev1_);
 	if (stream2_) { hipStreamSynchronize(stream2_); hipStreamDestroy(stream2_); }
+	for (int k = 0; k < 2; k++) { if (ev_ctl_[k]) hipEventDestroy(ev_ctl_[k]); ev_ctl_[k] = nullptr; }
 	if (ev_fork_) hipEventDestroy(ev_fork_);
 	if (ev_join_) hipEventDestroy(ev_join_);
 	stream2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
@@ -1190,7 +1191,10 @@ void Engine::ensure_queues(size_t nsearch)
 	}
 	if (!d_qctl_) {
 		HIPCHK(hipMalloc(&d_qctl_, sizeof(QCtl)));
-		HIPCHK(hipHostMalloc(&h_qctl_, sizeof(QCtl)));
+		HIPCHK(hipHostMalloc(&h_qctl_, sizeof(QCtl) * 2));
+		std::memset(h_qctl_, 0, sizeof(QCtl) * 2);
+		for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&ev_ctl_[k], hipEventDisableTiming));
+		{ const char* e = std::getenv("GOICP_QUEUE_AHEAD"); if (e) queue_ahead_ = std::atoi(e) != 0; }
 	}
 	cap_qsearch_ = cap;
 }
@@ -1240,7 +1244,9 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	int rounds_done = 0;
 	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
 	tile_hint_seen_ = 0;
-	while (true) {
+	// One chunk of rounds: queue kernel + (sort) + bound evaluation(s) per round, then the control block's read-back into snapshot `slot`.
+	int last_of[2] = {0, 0};
+	auto submit = [&](int slot) {
 		const double t0 = now_ms();
 		int last = 0;
 		const int max_groups = (int)std::min<size_t>(S * (size_t)std::min(qp.kmax, 4 * qp.K), (size_t)q_list_cap_);   // most the round can list (the kernel widens a stale search's step up to x4)
@@ -1272,34 +1278,70 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 			cnt_.bounds_launches++;
 			queue_rounds_++;
 		}
-		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(h_qctl_ + slot, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipEventRecord(ev_ctl_[slot], stream_));
+		last_of[slot] = last;
 		t_submit_ += now_ms() - t0;
-		const double t1 = now_ms();
-		HIPCHK(hipStreamSynchronize(stream_));
-		t_wait_ += now_ms() - t1;
-		if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-		if ((h_qctl_->n_groups[last] == 0 && h_qctl_->n_tile_groups[last] == 0) || cancel_.load()) break;
-		if (tiles && p_.lds_tiles == 2) { qp.tile_on = h_qctl_->tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = h_qctl_->tile_hint; }
+	};
+	// fold a chunk's read-back into the parameters of the chunks still to be queued
+	auto adapt = [&](const QCtl& c, int last) {
+		if (tiles && p_.lds_tiles == 2) { qp.tile_on = c.tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = c.tile_hint; }
 		// (later rounds of a batch are narrow -- their expansions lie close together whatever the order -- and in long registrations the three
 		// extra launches per round are not free on the host side: mse 1e-4 bunny 295 vs 302 ms with the sort queued in every wide round)
-		sort_round = qsort_.order != nullptr && h_qctl_->n_groups[last] >= qsort_.min_groups && rounds_done < 7;
+		sort_round = qsort_.order != nullptr && c.n_groups[last] >= qsort_.min_groups && rounds_done < 7;
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)
 		chunk = 4;
 		// exact: the searches that listed expansions in the last round (a search only ever finishes, so it bounds the rounds to come)
-		const int active = std::max(1, h_qctl_->n_active[last]);
+		const int active = std::max(1, c.n_active[last]);
 		qp.kmax = std::min(kQueueMaxPop, q_list_cap_ / active);
 		if (p_.adaptive_k && K >= 32) {
 			// <= 16 running: up to 512 expansions each (swept 1 / 2 / 4 / 8 / 16 searches: the same within the run-to-run spread)
 			qp.K = active <= 16 ? kQueueMaxPop : (active <= 64 ? std::min(kQueueRoundPop, 2 * K) : K);
 		}
+	};
+	auto wait_slot = [&](int slot) {
+		const double t1 = now_ms();
+		HIPCHK(hipEventSynchronize(ev_ctl_[slot]));
+		t_wait_ += now_ms() - t1;
+	};
+	if (!queue_ahead_) {
+		// lock-step with the host: queue a chunk, wait for it, look at it (the GPU idles ~45 us per chunk while the host decides)
+		while (true) {
+			submit(0);
+			wait_slot(0);
+			const QCtl& c = h_qctl_[0];
+			if (c.overflow) { HIPCHK(hipStreamSynchronize(stream_)); queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
+			if ((c.n_groups[last_of[0]] == 0 && c.n_tile_groups[last_of[0]] == 0) || cancel_.load()) break;
+			adapt(c, last_of[0]);
+		}
+	} else {
+		// one chunk ahead (A/B only): chunk k+1 is queued before chunk k's read-back is looked at, so the GPU never waits for the host; the parameters
+		// a read-back adapts (round width, tile / sort launches, list bound) reach the chunk after next -- all of them are conservative when late
+		// (searches only finish: an older `active` count bounds the lists from above).  A batch that has ended drains the chunk in flight as no-ops.
+		// Measured (tools/queue_ahead_probe.py): bunny 33.1 -> 32.7 ms, but skull 6.39 -> 6.50, S1 11.3 -> 11.8, bunny mse 3e-5 6.75 -> 7.59 s:
+		// the late round width costs more rounds than the ~45 us bubbles per chunk it removes
+		submit(0);
+		int cur = 0;
+		while (true) {
+			submit(cur ^ 1);
+			wait_slot(cur);
+			const QCtl& c = h_qctl_[cur];
+			if (c.overflow) { HIPCHK(hipStreamSynchronize(stream_)); queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
+			if ((c.n_groups[last_of[cur]] == 0 && c.n_tile_groups[last_of[cur]] == 0) || cancel_.load()) break;
+			adapt(c, last_of[cur]);
+			cur ^= 1;
+		}
 	}
-	cnt_.tile_expansions += h_qctl_->tile_total;
-	if (p_.verbose) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) sel_hist_[a][b] += h_qctl_->sel_hist[a][b];
+	// the running totals of the whole batch and the searches' results in one round trip (the chunk in flight, if any, was queued before these copies)
 	const double t2 = now_ms();
+	HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
+	if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
+	cnt_.tile_expansions += h_qctl_->tile_total;
+	if (p_.verbose) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) sel_hist_[a][b] += h_qctl_->sel_hist[a][b];
 	if (p_.verbose > 1 && now_ms() - t2 > 1.0) std::fprintf(stderr, "[goicp] slow read-back of %zu search records: %.2f ms\n", S, now_ms() - t2);
 	const double t3 = now_ms();
 	for (size_t i = 0; i < S; i++) {

@@ -274,7 +274,9 @@ private:
 	int q_seg_cap_ = 0;                                 // segments the tile list holds (q_list_cap_ / 64 + search slots)
 	int* d_qpsearch_[2] = {nullptr, nullptr};          // per listed expansion: the search that listed it (twin test of the bound evaluation)
 	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
-	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;
+	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;       // h_qctl_: two pinned snapshots (one per chunk of rounds in flight)
+	hipEvent_t ev_ctl_[2] = {nullptr, nullptr};
+	int queue_ahead_ = 0;                                   // env GOICP_QUEUE_AHEAD = 1 (A/B only): the host stays one chunk of rounds ahead of the read-backs.  Measured: no gain (EXPERIMENTS R4.9)
 	QTile qtile_{};                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
 	bool tiles_usable() const;
 	int tile_hint_seen_ = 0;              // QCtl::tile_hint at the last read-back

@@ -1591,182 +1591,6 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 	return r;
 }
 
-// ------------------------------------------------------------------------------------------------
-// PACKET walk (round 4): the four queries of a wavefront walk the hierarchy TOGETHER.  rows_nearest gives every 16-lane row its own walk:
-// each row evaluates all 64 child boxes of every group it enters (four per lane) and the four rows sit at different stages, so every loop
-// iteration issues every stage's code under exec masks -- 1 214 VALU instructions per wavefront on a kernel that is VALU-issue-bound.  When
-// the four queries are NEIGHBOURS (consecutive points of the k-d-ordered cloud: a patch a few voxels wide) their walks visit the same
-// groups and nearly the same leaves.  Here a LANE owns ONE child box of the current group and bounds it against the packet's bounding box
-// (64 box bounds per group and wavefront instead of 256), the nearest remaining child is a wave-wide minimum (scalar), control flow is
-// wave-uniform (no stages under masks), and a leaf scan uses all 64 lanes: lane (row r, slot l) computes |q_r - point l|.
-// Exactness: the packet bound of a box is <= every query's own box bound (float subtraction, max, square and the fixed-order sum are all
-// monotone, and min(q) <= q_r <= max(q) per axis), which is <= the distance to every point in the box (same accumulation order as the
-// point distance); a child is skipped only when its packet bound is STRICTLY above the largest of the four best distances, so no point
-// that could beat or tie any query's best is ever skipped; ties go to the lowest original index inside a scan exactly as in rows_nearest.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned rows_to_wave_min(unsigned row_uniform)     // min over the four rows of a row-uniform value: scalar
-{
-	const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 0), b = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 16);
-	const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 32), d = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 48);
-	return min(min(a, b), min(c, d));
-}
-__device__ __forceinline__ unsigned rows_to_wave_max(unsigned row_uniform)
-{
-	const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 0), b = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 16);
-	const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 32), d = (unsigned)__builtin_amdgcn_readlane((int)row_uniform, 48);
-	return max(max(a, b), max(c, d));
-}
-// take the nearest remaining child of the group (one key per lane): its key (scalar; 0xffffffff when none is left) and its index 0..63
-__device__ __forceinline__ unsigned packet_take(unsigned& key, int lane, int& child)
-{
-	const unsigned m = rows_to_wave_min(row_min_u32(key));
-	child = __ffsll((long long)__ballot(key == m)) - 1;
-	if (lane == child) key = 0xffffffffu;
-	return m;
-}
-struct PacketBox { float lox, loy, loz, hix, hiy, hiz; };
-__device__ __forceinline__ PacketBox packet_load_box(const float* __restrict__ g, int lane)     // child `lane` of the group at g (six runs of 64 floats)
-{
-	return PacketBox{g[lane], g[64 + lane], g[128 + lane], g[192 + lane], g[256 + lane], g[320 + lane]};
-}
-__device__ __forceinline__ unsigned packet_box_key(const PacketBox& b, const float (&pmin)[3], const float (&pmax)[3])
-{
-	const float ex = fmaxf(fmaxf(b.lox - pmax[0], pmin[0] - b.hix), 0.f);
-	const float ey = fmaxf(fmaxf(b.loy - pmax[1], pmin[1] - b.hiy), 0.f);
-	const float ez = fmaxf(fmaxf(b.loz - pmax[2], pmin[2] - b.hiz), 0.f);
-	float d = ex * ex;                                   // box_lb1's accumulation order
-	d += ey * ey;
-	d += ez * ez;
-	return __float_as_uint(d);
-}
-
-template <int K, int LAYOUT, int LEAVES = 4>
-__device__ __forceinline__ RowNn packet_nearest(const KdDesc& kd, const DtDesc& dt, int lane, int row, int l, float qx, float qy, float qz)
-{
-	// the packet's bounding box (scalars): min / max over the four rows' queries
-	float pmin[3], pmax[3];
-	{
-		const float q[3] = {qx, qy, qz};
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[k]), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[k]), 16));
-			const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[k]), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[k]), 48));
-			pmin[k] = fminf(fminf(a, b), fminf(c, d));
-			pmax[k] = fmaxf(fmaxf(a, b), fmaxf(c, d));
-		}
-	}
-	unsigned key[K];
-	int node[K];
-	node[0] = 0;
-	const PacketBox rb = packet_load_box(kd.boxes[0], lane);
-	// every row starts from a REAL candidate (the nearest-target-point table, as rows_nearest) or from the distance-transform bound
-	RowNn r{0.f, INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
-	int seed_slot = -1;
-	if (dt.nn_ids) {
-		const int V1 = dt.V - 1;
-		const int ix = min(max((int)rintf((qx - dt.xmin_f) * dt.scale_f), 0), V1);
-		const int iy = min(max((int)rintf((qy - dt.ymin_f) * dt.scale_f), 0), V1);
-		const int iz = min(max((int)rintf((qz - dt.zmin_f) * dt.scale_f), 0), V1);
-		size_t off;
-		if (LAYOUT == 0) off = ((size_t)iz * dt.V + iy) * dt.V + ix;
-		else off = (((size_t)(iz >> 2) * dt.VB + (iy >> 2)) * dt.VB + (ix >> 2)) * 64 + (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3));
-		seed_slot = dt.nn_ids[off];
-	}
-	key[0] = packet_box_key(rb, pmin, pmax);
-#pragma unroll
-	for (int L = 1; L < K; L++) { node[L] = 0; key[L] = 0xffffffffu; }
-	int d = 0;
-	if constexpr (K > 1) {
-		// the nearest child of the root survives any valid bound: its boxes are fetched beside the seed (one dependent round trip less)
-		int c;
-		packet_take(key[0], lane, c);
-		node[1] = c;
-		const PacketBox fb = packet_load_box(kd.boxes[1] + (size_t)node[1] * 384, lane);
-		key[1] = packet_box_key(fb, pmin, pmax);
-		d = 1;
-	}
-	if (seed_slot >= 0) {
-		const float4 pt = kd.pts[seed_slot];
-		const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
-		float e = d0 * d0;                                                 // the leaf scan's accumulation order: the same bits
-		e += d1 * d1;
-		e += d2 * d2;
-		r.best = e; r.idx = __float_as_int(pt.w); r.mine = l == 0; r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = seed_slot;
-	} else
-		r.best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
-	unsigned bbits = __float_as_uint(r.best);
-	unsigned maxb = rows_to_wave_max(bbits);                               // scalar: the largest of the four best distances
-	while (true) {
-		bool finished = false;
-#pragma unroll
-		for (int L = K - 1; L >= 0; L--) {
-			if (d == L) {                                                  // wave-uniform
-				int c;
-				const unsigned m = packet_take(key[L], lane, c);
-				if (m > maxb) {                                            // nothing left within any query's best distance
-					if (L == 0) finished = true; else d = L - 1;
-				} else if (L == K - 1) {
-					// ---- scan the LEAVES nearest remaining leaves of the group: all loads in flight, one wait; lane (row, l) holds slot l ----
-					const int s0 = (node[L] * 64 + c) * kLeafSlots + l;
-					int sl[LEAVES];
-					bool use[LEAVES];
-					sl[0] = s0; use[0] = true;
-#pragma unroll
-					for (int j = 1; j < LEAVES; j++) {
-						int cj;
-						const unsigned mj = packet_take(key[L], lane, cj);
-						use[j] = mj <= maxb;                               // a child beyond the bound is pruned for good (the bound only falls)
-						sl[j] = use[j] ? (node[L] * 64 + cj) * kLeafSlots + l : s0;
-					}
-					float4 pq[LEAVES];
-#pragma unroll
-					for (int j = 0; j < LEAVES; j++) pq[j] = kd.pts[sl[j]];
-					float4 pt = pq[0];
-					int sb = sl[0];
-					float e;
-					{
-						const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
-						e = d0 * d0;                                       // L2_Simple_Adaptor accumulation order
-						e += d1 * d1;
-						e += d2 * d2;
-					}
-#pragma unroll
-					for (int j = 1; j < LEAVES; j++) {
-						const float d0 = qx - pq[j].x, d1 = qy - pq[j].y, d2 = qz - pq[j].z;
-						float dj = d0 * d0;
-						dj += d1 * d1;
-						dj += d2 * d2;
-						const bool wins = use[j] && (dj < e || (dj == e && __float_as_int(pq[j].w) < __float_as_int(pt.w)));
-						if (wins) { pt = pq[j]; e = dj; sb = sl[j]; }
-					}
-					const unsigned db = __float_as_uint(e);
-					const unsigned dmin = row_min_u32(db);
-					const unsigned id = (unsigned)__float_as_int(pt.w);
-					const unsigned idmin = row_min_u32(db == dmin ? id : 0x7fffffffu);   // ties -> lowest original index
-					if (dmin < bbits || (dmin == bbits && (int)idmin < r.idx)) {
-						bbits = dmin;
-						r.idx = (int)idmin;
-						r.mine = db == dmin && id == idmin;
-						r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = sb;
-					}
-					maxb = rows_to_wave_max(bbits);
-				} else {
-					// ---- enter the nearest remaining child group one level down ----
-					const int NL = L + 1 < K ? L + 1 : L;
-					node[NL] = node[L] * 64 + c;
-					const PacketBox cb = packet_load_box(kd.boxes[NL] + (size_t)node[NL] * 384, lane);
-					key[NL] = packet_box_key(cb, pmin, pmax);
-					d = NL;
-				}
-				break;                                                     // one step per iteration
-			}
-		}
-		if (finished) break;
-	}
-	r.best = __uint_as_float(bbits);
-	return r;
-}
-
 // Workgroup-shared state of one ICP iteration: the per-wavefront sums of the pass and the finalize's scratch, in ONE
 // __shared__ object (a second one beside it can make the compiler drain the memory pipeline before LDS reads).
 constexpr int kFinThreads = 1024;                  // the stand-alone finalize: 256 row streams x four float4 columns
@@ -1780,7 +1604,7 @@ __device__ __forceinline__ void finalize_rows(const double* __restrict__ sums, I
 // nn_cache (two float4 per source point: {q_ref.xyz, sqrt(best2_ref)}, {neighbour xyz, its original index}) != nullptr:
 // the exact skip test of rows_nearest<TWO>'s comment; entries never go stale (they are statements about the static
 // target cloud), an entry with sqrt(best2_ref) = 0 (fresh engine, tied neighbours) always walks.
-template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2, bool STRIDED = false, bool ACC = false, bool PACKET = false>
+template <int K, int LAYOUT, bool FUSED, bool CACHE, int LEAVES = 2, bool STRIDED = false, bool ACC = false>
 __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kernel(const float4* __restrict__ src, int N,
                                                                   IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
                                                                   float* __restrict__ partials, int* __restrict__ ticket,
@@ -1827,13 +1651,6 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 			nn_cache[2 * (size_t)i] = make_float4(qx, qy, qz, __fsqrt_rn(r.best2) * 0.99999f);
 			nn_cache[2 * (size_t)i + 1] = make_float4(r.mx, r.my, r.mz, __int_as_float(r.idx));
 		}
-	} else if constexpr (PACKET) {
-		// the four (neighbouring) queries of the wavefront walk together; a row without a query shadows row 0 so that the packet's box stays tight
-		static_assert(!STRIDED, "a packet is four NEIGHBOURS of the k-d order");
-		const float px = valid ? qx : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), 0));
-		const float py = valid ? qy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), 0));
-		const float pz = valid ? qz : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), 0));
-		r = packet_nearest<K, LAYOUT, 4>(kd, dt, lane, row, l, px, py, pz);
 	} else {
 		r = rows_nearest<K, LAYOUT, false, LEAVES>(kd, dt, rootb, l, row, qx, qy, qz, valid);
 	}
@@ -2512,15 +2329,11 @@ int icp_blocks(int N)
 // kIcpStridedMaxN points, neighbours above
 template <int K>
 static void launch_pass_acc(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, unsigned long long* acc, float4* nn_cache,
-                            int* hits, hipStream_t stream, bool packet)
+                            int* hits, hipStream_t stream)
 {
 	const dim3 grid(icp_blocks(N)), block(kIcpThreads);
 	float* a = reinterpret_cast<float*>(acc);
 	const bool strided = N <= kIcpStridedMaxN;
-	if (packet && !nn_cache) {
-		hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, false, 4, false, true, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
-		return;
-	}
 	if (nn_cache) {
 		if (strided) hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, true, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
 		else hipLaunchKernelGGL((icp_pass_kernel<K, 1, false, true, 2, false, true>), grid, block, 0, stream, src, N, st, kd, dt, a, nullptr, nn_cache, hits);
@@ -2571,13 +2384,13 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 
 // ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc, bool packet)
+                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc)
 {
 	if (!ticket && acc && dt.layout) {
 		// the default form: fixed-point sums, no rows of partial sums
-		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream, packet);
-		else if (kd.K == 2) launch_pass_acc<2>(src, N, st, kd, dt, acc, nn_cache, hits, stream, packet);
-		else launch_pass_acc<3>(src, N, st, kd, dt, acc, nn_cache, hits, stream, packet);
+		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
+		else if (kd.K == 2) launch_pass_acc<2>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
+		else launch_pass_acc<3>(src, N, st, kd, dt, acc, nn_cache, hits, stream);
 		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinAccThreads), 0, stream, acc, st);
 		return hipGetLastError();
 	}
@@ -2661,7 +2474,7 @@ hipError_t launch_reduce_min(const float* v, int n, float* out_min, int* out_idx
 	return hipGetLastError();
 }
 
-template <int K, int LAYOUT, bool PACKET = false>
+template <int K, int LAYOUT>
 __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __restrict__ q, int n, KdDesc kd, DtDesc dt,
                                                                int32_t* __restrict__ idx, float* __restrict__ d2)
 {
@@ -2670,31 +2483,24 @@ __global__ __launch_bounds__(kIcpThreads) void nn_query_kernel(const float* __re
 	const bool valid = i < n;
 	const int iq = valid ? i : n - 1;
 	const float qx = q[3 * iq], qy = q[3 * iq + 1], qz = q[3 * iq + 2];
-	RowNn r;
-	if constexpr (PACKET) r = packet_nearest<K, LAYOUT, 4>(kd, dt, lane, row, l, qx, qy, qz);      // (rows without a query repeat the last one: inside the packet's box)
-	else r = rows_nearest<K, LAYOUT, false, 4>(kd, dt, load_child_boxes4(kd.boxes[0], l), l, row, qx, qy, qz, valid);
+	const RowNn r = rows_nearest<K, LAYOUT, false, 4>(kd, dt, load_child_boxes4(kd.boxes[0], l), l, row, qx, qy, qz, valid);
 	if (valid && r.mine) { idx[i] = r.idx; d2[i] = r.best; }
 }
 
 template <int K>
-static void launch_nn_k(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream, bool packet)
+static void launch_nn_k(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
 {
 	const dim3 grid(icp_blocks(n)), block(kIcpThreads);
-	if (packet) {
-		if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<K, 1, true>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
-		else hipLaunchKernelGGL((nn_query_kernel<K, 0, true>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
-		return;
-	}
 	if (dt.layout) hipLaunchKernelGGL((nn_query_kernel<K, 1>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 	else hipLaunchKernelGGL((nn_query_kernel<K, 0>), grid, block, 0, stream, q, n, kd, dt, idx, d2);
 }
 
-hipError_t launch_nn_query(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream, bool packet)
+hipError_t launch_nn_query(const float* q, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2, hipStream_t stream)
 {
 	if (n <= 0) return hipSuccess;
-	if (kd.K == 1) launch_nn_k<1>(q, n, kd, dt, idx, d2, stream, packet);
-	else if (kd.K == 2) launch_nn_k<2>(q, n, kd, dt, idx, d2, stream, packet);
-	else launch_nn_k<3>(q, n, kd, dt, idx, d2, stream, packet);
+	if (kd.K == 1) launch_nn_k<1>(q, n, kd, dt, idx, d2, stream);
+	else if (kd.K == 2) launch_nn_k<2>(q, n, kd, dt, idx, d2, stream);
+	else launch_nn_k<3>(q, n, kd, dt, idx, d2, stream);
 	return hipGetLastError();
 }
 

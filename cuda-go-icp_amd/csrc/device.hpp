@@ -232,8 +232,7 @@ size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_i
 // acc: kIcpAccReplicas x 16 zeroed 64-bit words (kept zero between iterations by the finalize) -> clouds of up to kIcpStridedMaxN
 // points sum there instead of writing a row of partial sums per workgroup; nullptr -> rows for every size
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr,
-                                bool packet = false);     // packet: the four NEIGHBOURING queries of a wavefront walk the hierarchy together (device.hip packet_nearest; acc form only)
+                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
@@ -242,7 +241,7 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 hipError_t launch_transform(float4* src, int N, const Pose& pose, hipStream_t stream);
 // NN operator on arbitrary queries (kernKDSearchNearest, icp_kernel.cu:146-157)
 hipError_t launch_nn_query(const float* q_xyz, int n, const KdDesc& kd, const DtDesc& dt, int32_t* idx, float* d2,
-                           hipStream_t stream, bool packet = false);
+                           hipStream_t stream);
 
 // min of n floats (+ first index attaining it, may be null): one workgroup; v must be 16-byte aligned
 hipError_t launch_reduce_min(const float* v, int n, float* out_min, int* out_idx, hipStream_t stream);

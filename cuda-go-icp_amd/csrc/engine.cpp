@@ -774,7 +774,7 @@ void Engine::nn_query(const float* q, size_t n, int32_t* idx, float* d2)
 	int32_t* di = reinterpret_cast<int32_t*>(base + sizeof(float) * 3 * n);
 	float* dd = reinterpret_cast<float*>(base + sizeof(float) * 4 * n);
 	HIPCHK(hipMemcpyAsync(dq, q, sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream_));
-	HIPCHK(launch_nn_query(dq, (int)n, kd_, dt_, di, dd, stream_, p_.icp_packet == 1));
+	HIPCHK(launch_nn_query(dq, (int)n, kd_, dt_, di, dd, stream_));
 	HIPCHK(hipMemcpyAsync(idx, di, sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipMemcpyAsync(d2, dd, sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
@@ -841,7 +841,7 @@ void Engine::icp_launch_one()
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
 		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
-		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_, icp_packet_on()));
+		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
 }
 
 void Engine::icp_state_fetch()

@@ -53,8 +53,6 @@ struct Params {
 	int stale_compact = 2048;     // a proving inner search whose queue holds at least this many nodes selects by Morton order of the cubes' corners instead of by lower
 	                              // bound (spatially compact, depth-first-like: LDS-tile material, and the slab stops overflowing); 0: always by lower bound
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
-	int icp_packet = -1;          // the ICP neighbour search walks the hierarchy per PACKET of four neighbouring queries (device.hip packet_nearest): 1 always (the NN
-	                              // operator too), 0 never (a walk per query, strangers per wavefront up to 40 k points), -1 by the size rule measured in EXPERIMENTS R4.10
 	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -294,7 +292,6 @@ private:
 	int* d_icp_ticket_ = nullptr;      // arrival ticket of the fused ICP iteration (zero between launches)
 	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only
 	void icp_launch_one();
-	bool icp_packet_on() const { return p_.icp_packet == 1 || (p_.icp_packet < 0 && false); }     // size rule: filled in after the measurement
 	// nn query staging grows on demand
 	float rot_coeff_[20];
 

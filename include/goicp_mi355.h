@@ -176,9 +176,6 @@ typedef struct goicp_params {
 	                          * (jly_goicp.cpp:257) has to be expanded whatever the order, a run of Morton-neighbours is spatially compact (LDS-tile
 	                          * material) and is explored depth-first-like, so the queue slab stops overflowing into the host fall-back.  0: always
 	                          * by lower bound (the reference's order, jly_goicp.h:64-71) */
-	int32_t icp_packet;      /* -1 (default): by the engine's size rule; 1: the ICP neighbour search (and goicp_nn_query) walks the box hierarchy per PACKET of four
-	                          * neighbouring queries -- one wave-uniform walk against the packet's bounding box, 64 box bounds per group and wavefront instead
-	                          * of 256 -- 0: a walk per query.  Exact either way (bit-equal neighbours and distances) */
 	int32_t stream_priority; /* 0 (default): the engine's HIP stream has the default priority; 1: the highest the device offers (hipStreamCreateWithPriority)
 	                          * -- for a latency-bound engine (an ICP loop) that shares the GPU with a throughput engine; measured: tools/overlap_probe.py */
 } goicp_params;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""ICP neighbour search: walks seeded from the distance-transform bound (icp_packet 0: a walk per query) against the PACKET walk (1: four neighbouring queries walk together; was: DT-bound vs point seeds
+"""[runs against commit 4447c64 only: the packet walker (Params::icp_packet) was removed after this measurement -- EXPERIMENTS R4.10]
+ICP neighbour search: walks seeded from the distance-transform bound (icp_packet 0: a walk per query) against the PACKET walk (1: four neighbouring queries walk together; was: DT-bound vs point seeds
 nearest-target-point table (1): engine creation, iterations/s of one forced 200-iteration trajectory, pass + finalize time at
 the identity pose and at the ICP optimum (HIP events), and identical results."""
 import ctypes as C

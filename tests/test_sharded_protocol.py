@@ -61,6 +61,34 @@ def test_library_protocol_thread_ranks(fe_mod, single, world, rebalance, stale):
         assert stats[0]["donations"] == 0
 
 
+class _Widths:
+    """Records the width (max_rot_pops) of every step the protocol asks a FakeEngine for."""
+
+    def __init__(self, inner):
+        self._e, self.widths = inner, []
+
+    def __getattr__(self, k):
+        return getattr(self._e, k)
+
+    def register_step(self, max_pops):
+        self.widths.append(int(max_pops))
+        return self._e.register_step(max_pops)
+
+
+@pytest.mark.parametrize("world,stale", [(1, False), (3, False), (2, True)])
+def test_step_ramp(fe_mod, single, world, stale):
+    """goicp_shard_options.ramp_to (ABI 4): the step width doubles from rot_pops_per_step up to ramp_to -- 2, 4, 8, 12, 12 ... -- on every
+    rank alike, through the Python -> C option struct; the run still reaches the single-rank optimum."""
+    from cuda_go_icp_amd import sharded
+    engines = [_Widths(e) for e in _engines(fe_mod, world)]
+    stats = sharded.run_thread_ranks([sharded.engine_ops(e) for e in engines], rot_pops_per_step=2, stale=stale, ramp_to=12)
+    assert all(s["status"] == 0 for s in stats)
+    for e in engines:
+        assert e.widths == engines[0].widths and e.widths[:4] == [2, 4, 8, 12][:len(e.widths)] and all(w == 12 for w in e.widths[3:])
+    s0, _, _ = single
+    assert abs(engines[0].pose()[0] - s0) <= float(engines[0].sse_threshold)
+
+
 class _Failing:
     """Fault injection around a FakeEngine: register_step raises on its `at`-th call."""
 

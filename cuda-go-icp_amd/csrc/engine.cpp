@@ -445,6 +445,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	HIPCHK(hipMemsetAsync(d_icp_acc_, 0, sizeof(unsigned long long) * kIcpAccReplicas * kIcpAcc, stream_));
 	for (size_t i = 0; i < N_; i++) src_radius_ = std::max(src_radius_, h_src_sorted_[4 * i + 3]);
 	for (size_t i = 0; i < 3 * M_; i++) target_abs_max_ = std::max(target_abs_max_, std::fabs(target[i]));
+	if (const char* e = std::getenv("GOICP_ICP_CACHE_REL")) { const float v = (float)std::atof(e); if (v > 0.f) icp_cache_rel_ = v; }     // tuning only
 	if (p_.icp_nn_cache) {
 		HIPCHK(hipMalloc(&d_nn_cache_, sizeof(float4) * 2 * N_));
 		HIPCHK(hipMemsetAsync(d_nn_cache_, 0, sizeof(float4) * 2 * N_, stream_));      // sqrt(best2_ref) = 0: the first pass walks
@@ -808,6 +809,7 @@ void Engine::source_transformed(const float R[9], const float t[3], float* out)
 void Engine::icp_state_init(const float R[9], const float t[3], float err_diff, int carry_means, int frozen)
 {
 	IcpState& st = *h_icp_state_;
+	icp_cache_active_ = false;          // icp_nn_cache = 2: every run starts with plain walks
 	std::memset(&st, 0, sizeof(st));
 	std::memcpy(st.R, R, sizeof(st.R));
 	std::memcpy(st.t, t, sizeof(st.t));
@@ -841,7 +843,7 @@ void Engine::icp_launch_one()
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
 		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
-		                            p_.icp_nn_cache ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
+		                            (p_.icp_nn_cache == 1 || icp_cache_active_) ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
 }
 
 void Engine::icp_state_fetch()
@@ -873,11 +875,18 @@ float Engine::icp_run(float R[9], float t[3], int max_iter, float err_diff, int*
 	int cur = 0;
 	bool have = submit(0);
 	const IcpState* fin = nullptr;
+	float prev_err = -1.f;
 	while (have) {
 		const bool next = submit(cur ^ 1);
 		HIPCHK(hipEventSynchronize(evs[cur]));
 		fin = &slots[cur];
 		if (fin->converged || cancel_.load()) break;
+		// icp_nn_cache = 2: the exact walk-skipping cache pays once the cloud has nearly stopped moving (the tail of a run: a cached neighbour stays
+		// provably nearest for many iterations) and loses while it still moves (every miss is a slower 2-nearest walk) -- so it is switched on, for
+		// the chunks queued from here on, when the error fell by less than icp_cache_rel_ over the last chunk.  Exact either way: bit-identical states
+		if (p_.icp_nn_cache == 2 && d_nn_cache_ && !icp_cache_active_ && prev_err > 0.f && fin->err > 0.f && (prev_err - fin->err) < icp_cache_rel_ * fin->err)
+			icp_cache_active_ = true;
+		prev_err = fin->err;
 		have = next;
 		cur ^= 1;
 	}
@@ -900,6 +909,7 @@ float Engine::time_icp_pass(const float R[9], const float t[3], int iters, bool 
 	struct Restore { int& r; int v; ~Restore() { r = v; } } restore{p_.icp_nn_cache, keep};
 	if (!cached) p_.icp_nn_cache = 0;
 	else if (!d_nn_cache_) throw std::invalid_argument("goicp: the neighbour cache is disabled for this engine");
+	else p_.icp_nn_cache = 1;
 	icp_state_init(R, t, 0.f, 0, 1);
 	icp_launch_one();
 	HIPCHK(hipStreamSynchronize(stream_));

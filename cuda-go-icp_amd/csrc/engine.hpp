@@ -30,7 +30,9 @@ struct Params {
 	int icp_chunk = 16;           // ICP iterations queued per host round trip
 	int kd_gpu_build = -1;        // box hierarchy built on the device (Morton sort, looser boxes): 1 yes, 0 / -1 host median splits (threaded)
 	int bounds_fp16 = 0;          // 1: BnB cube bounds read a half-precision copy of the bricked DT (rounded toward zero: lower bounds stay valid, upper bounds low by <= 2^-10 relative); ICP, the DT re-score and trimmed bounds keep the fp32 grid.  Not bit-parity: opt-in
-	int icp_nn_cache = 0;         // 1: an ICP pass skips (exactly) the tree walk of every query whose cached neighbour is provably still the nearest (measured slower on real trajectories, DESIGN 3.6: opt-in); 0: every query walks every pass; bit-identical states either way
+	int icp_nn_cache = 0;         // 1: an ICP pass skips (exactly) the tree walk of every query whose cached neighbour is provably still the nearest (measured slower on real trajectories, EXPERIMENTS 3.6: opt-in);
+	                              // 2: the same, switched on inside a run only once the error falls by < 2 % per 16 iterations (the tail; measured +0..3 %, EXPERIMENTS R4.11: opt-in);
+	                              // 0: every query walks every pass; bit-identical states in every mode
 	int flow = 0;                 // opt-in; L > 0: continuous flow over the device queues -- rotation children are harvested one by one and the next batch of parents is admitted when at most this many inner searches still run; 0: lock-step batches
 	int adaptive_k = 1;           // 1: when few inner searches still run, each may expand up to 512 nodes per round instead of trans_batch
 	int queue_cap = 0;            // test hook: nodes a device queue may hold before the batch falls back to the host queues (0 = the full slab)
@@ -288,6 +290,8 @@ private:
 	unsigned long long* d_icp_acc_ = nullptr;   // fixed-point sums of the small-cloud ICP pass (kIcpAccReplicas x 16, zero between iterations)
 	float src_radius_ = 0.f, target_abs_max_ = 0.f;   // extents that bound the pass's terms (IcpState::acc_scale)
 	float4* d_nn_cache_ = nullptr;     // per source point: {q_ref, sqrt(best2_ref)}, {neighbour, index} (exact walk-skipping, device.hip)
+	bool icp_cache_active_ = false;    // icp_nn_cache = 2: switched on inside a run once the error's decrease per chunk falls under icp_cache_rel_ (the tail of a run)
+	float icp_cache_rel_ = 0.02f;
 	bool count_hits_ = false;
 	int* d_icp_ticket_ = nullptr;      // arrival ticket of the fused ICP iteration (zero between launches)
 	float* d_nn_d2_ = nullptr; int* d_nn_slot_ = nullptr; unsigned char* d_include_ = nullptr;   // trimmed ICP only

@@ -176,6 +176,7 @@ typedef struct goicp_params {
 	                          * (jly_goicp.cpp:257) has to be expanded whatever the order, a run of Morton-neighbours is spatially compact (LDS-tile
 	                          * material) and is explored depth-first-like, so the queue slab stops overflowing into the host fall-back.  0: always
 	                          * by lower bound (the reference's order, jly_goicp.h:64-71) */
+	/* (icp_nn_cache, above: 2 = the exact neighbour cache switched on in the tail of a run only -- round 4, measured +0..3 %, opt-in) */
 	int32_t stream_priority; /* 0 (default): the engine's HIP stream has the default priority; 1: the highest the device offers (hipStreamCreateWithPriority)
 	                          * -- for a latency-bound engine (an ICP loop) that shares the GPU with a throughput engine; measured: tools/overlap_probe.py */
 } goicp_params;

@@ -245,6 +245,14 @@ def test_bench_plain_launch_two_ranks_gloo():
     assert len(lines) == 1 and not [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("{")]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["metric"] == "bnb_cube_bounds_per_s"
+    # the driver's contract: the keys of the ONE line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in j["roofline"], k
+    assert abs(j["value"] - 2 * j["config"]["cubes_per_step_per_gpu"] * 3 / (j["ms_per_step"] * 3e-3)) <= 0.01 * j["value"]     # value = units of all ranks / the timed region
     sh = j["e2e_sharded"]
     assert "error" not in sh and "error" not in sh["spanner"] and sh["spanner"]["bulk_synchronous"]["sse"] < sh["spanner"]["bulk_synchronous"]["sse_threshold"]
     d = sh["deep"]

@@ -129,11 +129,32 @@ def sub_configs(h, tmp):
     print("sub-config fixtures written to", OUT)
 
 
+def small_e2e(h, tmp, seeds=(1, 4, 6, 8)):
+    """Small seeded problems whose optimum the reference has to PROVE (tests/conftest.py small_problem: 400-point target, 150-point source, mse
+    1e-3; the optimum's SSE 0.5-0.7 stays above SSEThresh 0.15, so GoICP::Register runs its outer BnB to convergence: 7-18 k rotation nodes,
+    9-19 M translation nodes, 10-21 minutes of CPU each -- seeds 2, 3, 5, 7 did not finish in 25 minutes and were left out) ->
+    tests/golden/e2e_small<seed>.json.  The converged-search counterpart of the early-exit fixtures."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import small_problem
+    os.makedirs(tmp, exist_ok=True)
+    procs = []
+    for s in seeds:
+        tgt, src, _, _ = small_problem(s)
+        ft, fs = os.path.join(tmp, "small_t%d.txt" % s), os.path.join(tmp, "small_s%d.txt" % s)
+        f32_to_txt(tgt, ft)
+        f32_to_txt(src, fs)
+        procs.append(subprocess.Popen([h, "e2e", OUT, "small%d" % s, ft, fs, "1e-3", "1"], stdout=subprocess.DEVNULL))
+    if any(p.wait() for p in procs):
+        sys.exit("harness failed")
+    print("small e2e fixtures written to", OUT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--sub-configs", action="store_true", help="only the strided skull / spanner fixtures (configs[2], [3])")
     ap.add_argument("--clouds-only", action="store_true", help="only (re)write the input-cloud blobs")
+    ap.add_argument("--small-e2e", action="store_true", help="only the small prove-the-optimum fixtures e2e_small<seed>.json (~20 minutes of CPU)")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present: fixtures can only be regenerated in the build container")
@@ -142,6 +163,8 @@ def main():
     h = os.path.join(HERE, "_ref", "ref_harness")
     if args.sub_configs:
         return sub_configs(h, "/tmp/goicp_gen_golden")
+    if args.small_e2e:
+        return small_e2e(h, "/tmp/goicp_gen_golden")
     mb, db = os.path.join(BUNNY, "model_bunny.txt"), os.path.join(BUNNY, "data_bunny.txt")
     mr, dr = os.path.join(BUNNY, "model_rand.txt"), os.path.join(BUNNY, "data_rand.txt")
     for name, src in (("model_bunny", mb), ("data_bunny", db), ("model_rand", mr), ("data_rand", dr)):

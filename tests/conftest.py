@@ -56,6 +56,27 @@ def skull_problem():
     return target, source, Rgt, tgt
 
 
+def small_problem(seed):
+    """Seeded small registration problem (tests/golden/e2e_small<seed>.json; oracle/gen_golden.py --small-e2e feeds the same clouds to the
+    reference's own GoICP::Register): target = 400 points, source = 150 points of a seeded star-shaped surface (cuda-go-icp_amd/synth.py),
+    the source under a seeded rigid motion (rotation anywhere in the pi-ball, translation within 0.25 per axis) + N(0, 0.004^2) noise.
+    The sparse target leaves the optimum's SSE (0.5-0.7) ABOVE SSEThresh (mse 1e-3 x 150 = 0.15): no early exit -- the reference has to
+    prove the optimum (7-18 k rotation nodes, 9-19 M translation nodes, 10-21 minutes of CPU).  Returns (target, source, R_gt, t_gt)."""
+    load_pkg()
+    from cuda_go_icp_amd import synth
+    amp = (0.35, 0.25, 0.30, 0.20, 0.35, 0.15, 0.28, 0.22)[seed % 8]
+    tgt, src, R0, t0 = synth.make_pair(seed=7000 + seed, M=400, N=150, noise=0.004, amp=amp)
+    rng = np.random.default_rng(9000 + seed)
+    while True:
+        v = rng.uniform(-np.pi, np.pi, 3)
+        if np.linalg.norm(v) <= np.pi:
+            break
+    Rx = synth._rodrigues(v)
+    tx = rng.uniform(-0.25, 0.25, 3)
+    s2 = ((src.astype(np.float64) - tx) @ Rx).astype(np.float32)          # src = Rx s2 + tx  =>  target ~= R0 Rx s2 + R0 tx + t0
+    return tgt, s2, R0 @ Rx, R0 @ tx + t0
+
+
 def rot_angle(Ra, Rb):
     """Geodesic angle between two rotations, from the chord ||Ra-Rb||_F = 2*sqrt(2)*sin(theta/2)
     (well conditioned near 0, unlike arccos of the trace)."""

@@ -503,6 +503,38 @@ def _e2e_counts(eng, g):
     assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"], (c.trans_pops, g["tNodeCount"])
 
 
+@pytest.mark.parametrize("seed", [1, 4, 6, 8])
+def test_e2e_small_proven_optimum(pkg, seed):
+    """The converged-search counterpart of the early-exit fixtures: small seeded problems (conftest.small_problem: 400-point target, 150-point
+    source, mse 1e-3) whose optimum scores ABOVE SSEThresh, so the reference's own GoICP::Register (tests/golden/e2e_small<seed>.json) runs its
+    outer BnB to convergence -- 7-18 k rotation nodes, 9-19 M translation nodes, 10-21 minutes of CPU -- and PROVES the optimum to within
+    SSEThresh.  The engine's default (widened, device-queue) search proves it too: its SSE lies within SSEThresh of the reference's (both are
+    within SSEThresh of the global optimum from above).  Measured (round 4): the SAME optimum -- SSE equal to 7 digits, pose to 5e-7 rad / 1e-7
+    -- in 0.24-0.53 s against 638-1 288 s, and, although the visit order differs, nearly the same search: 12 457 / 9 965 / 7 407 / 18 256
+    rotation nodes against the reference's 12 455 / 9 965 / 7 403 / 18 248, cube bounds within 2 % of 8 x its tNodeCount (a converged BnB has
+    to expand every node whose lower bound stays SSEThresh under the optimum, whatever the order).  Bars: pose 1e-5, rotation nodes 1 %,
+    cube bounds 5 %."""
+    from conftest import small_problem
+    tgt, src, _, _ = small_problem(seed)
+    g = golden("e2e_small%d" % seed)
+    assert g["sse"] > g["sse_threshold"] and g["rNodeCount"] > 5000          # the point of these fixtures: no early exit
+    eng = pkg.FastGoICP(tgt, src, g["mse_threshold"])
+    import time
+    t0 = time.perf_counter()
+    eng.run()
+    wall = time.perf_counter() - t0
+    sse = float(eng.get_best_error())
+    ang, dt = rot_angle(eng.optR, np.array(g["R"])), float(np.linalg.norm(eng.optT - np.array(g["t"])))
+    c = eng.counters
+    print("e2e small%d: %.3f s (reference CPU %.0f s), sse %.6g (reference %.6g), rot_error %.3e trans_error %.3e, rotation nodes %d (reference %d), cube bounds %d (reference <= %d)"
+          % (seed, wall, g["register_s"], sse, g["sse"], ang, dt, c.rot_pops, g["rNodeCount"], c.cubes, 8 * g["tNodeCount"]))
+    assert eng.finished and abs(sse - g["sse"]) <= 1e-5 * g["sse"]
+    assert ang <= 1e-5 and dt <= 1e-5, (ang, dt)
+    assert abs(c.rot_pops - g["rNodeCount"]) <= 0.01 * g["rNodeCount"]
+    assert abs(c.cubes - 8 * g["tNodeCount"]) <= 0.05 * 8 * g["tNodeCount"]
+    eng.registration.close()
+
+
 def test_e2e_skull_sub_reference_order(pkg):
     """BASELINE configs[2] pinned to the reference: the real GoICP::Register (src/goicp/jly_goicp.cpp:569-585) on the
     skull scan (98 359-point target, the DT over all of it) and every 10th point of the known-motion source

@@ -144,6 +144,14 @@ def small_e2e(h, tmp, seeds=(1, 4, 6, 8)):
         f32_to_txt(tgt, ft)
         f32_to_txt(src, fs)
         procs.append(subprocess.Popen([h, "e2e", OUT, "small%d" % s, ft, fs, "1e-3", "1"], stdout=subprocess.DEVNULL))
+    # ... and the tiny ones (200 x 60 points, mse 5e-3: converged after 1.2-2.4 k rotation nodes, seconds of CPU) for the reference-order mode
+    from conftest import tiny_problem
+    for s in (1, 2, 3, 6):
+        tgt, src = tiny_problem(s)
+        ft, fs = os.path.join(tmp, "tiny_t%d.txt" % s), os.path.join(tmp, "tiny_s%d.txt" % s)
+        f32_to_txt(tgt, ft)
+        f32_to_txt(src, fs)
+        procs.append(subprocess.Popen([h, "e2e", OUT, "tiny%d" % s, ft, fs, "5e-3", "1"], stdout=subprocess.DEVNULL))
     if any(p.wait() for p in procs):
         sys.exit("harness failed")
     print("small e2e fixtures written to", OUT)

@@ -77,6 +77,24 @@ def small_problem(seed):
     return tgt, s2, R0 @ Rx, R0 @ tx + t0
 
 
+def tiny_problem(seed):
+    """The same construction at 200 target / 60 source points, registered at mse 5e-3 (SSEThresh 0.3 under the optimum's 0.35-0.55: the reference
+    proves the optimum in 1.2-2.4 k rotation / 0.1-0.25 M translation nodes, 3-6 s of CPU): small enough for the engine's REFERENCE-ORDER mode
+    (one expansion per launch) and for the CPU oracle -- tests/golden/e2e_tiny<seed>.json.  Returns (target, source)."""
+    load_pkg()
+    from cuda_go_icp_amd import synth
+    amp = (0.35, 0.25, 0.30, 0.20)[seed % 4]
+    tgt, src, _, _ = synth.make_pair(seed=7100 + seed, M=200, N=60, noise=0.004, amp=amp)
+    rng = np.random.default_rng(9100 + seed)
+    while True:
+        v = rng.uniform(-np.pi, np.pi, 3)
+        if np.linalg.norm(v) <= np.pi:
+            break
+    Rx = synth._rodrigues(v)
+    tx = rng.uniform(-0.25, 0.25, 3)
+    return tgt, ((src.astype(np.float64) - tx) @ Rx).astype(np.float32)
+
+
 def rot_angle(Ra, Rb):
     """Geodesic angle between two rotations, from the chord ||Ra-Rb||_F = 2*sqrt(2)*sin(theta/2)
     (well conditioned near 0, unlike arccos of the trace)."""

@@ -535,6 +535,38 @@ def test_e2e_small_proven_optimum(pkg, seed):
     eng.registration.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 6])
+def test_e2e_tiny_proven_optimum_reference_order(pkg, seed):
+    """A CONVERGED search in the reference's own visit order (trans_batch = 1, wide_children = 0: one expansion per launch, host queues): tiny
+    seeded problems (conftest.tiny_problem, 200 x 60 points, mse 5e-3) on which the reference's GoICP::Register proves the optimum
+    (tests/golden/e2e_tiny<seed>.json: 1 201-2 277 rotation nodes, 0.11-0.25 M translation nodes).  Measured (round 4): the same optimum to 7
+    digits, the rotation-node counts IDENTICAL (1 609 / 1 857 / 1 201 / 2 277), the translation-node counts identical on three of the four
+    (202 740, 107 515, 248 359) and 177 133 against 177 135 on the fourth (float sums in another order flip a prune decision now and then).
+    Bars: rotation nodes equal, translation nodes within 0.1 %."""
+    from conftest import tiny_problem
+    tgt, src = tiny_problem(seed)
+    g = golden("e2e_tiny%d" % seed)
+    assert g["sse"] > g["sse_threshold"] and g["rNodeCount"] > 1000
+    eng = pkg.FastGoICP(tgt, src, g["mse_threshold"], trans_batch=1, wide_children=0)
+    eng.run()
+    sse, c = float(eng.get_best_error()), eng.counters
+    ang, dt = rot_angle(eng.optR, np.array(g["R"])), float(np.linalg.norm(eng.optT - np.array(g["t"])))
+    print("e2e tiny%d reference order: sse %.7g (reference %.7g) rot_error %.2e trans_error %.2e rotation nodes %d (reference %d) translation nodes %d (reference %d)"
+          % (seed, sse, g["sse"], ang, dt, c.rot_pops, g["rNodeCount"], c.trans_pops, g["tNodeCount"]))
+    assert eng.finished and abs(sse - g["sse"]) <= 1e-5 * g["sse"] and ang <= 1e-5 and dt <= 1e-5
+    assert c.rot_pops == g["rNodeCount"]
+    assert abs(c.trans_pops - g["tNodeCount"]) <= 1e-3 * g["tNodeCount"]
+    eng.registration.close()
+    # the default (widened) search proves the same optimum
+    eng = pkg.FastGoICP(tgt, src, g["mse_threshold"])
+    eng.run()
+    assert abs(float(eng.get_best_error()) - g["sse"]) <= 1e-5 * g["sse"] and rot_angle(eng.optR, np.array(g["R"])) <= 1e-5
+    # (batches of up to 64 parents expand a few cubes a one-at-a-time order would have pruned first: + 8 ... 12 % on these 1.2-2.3 k nodes, + 0.1 % on the 7-18 k of e2e_small*)
+    print("e2e tiny%d default mode: rotation nodes %d (reference %d)" % (seed, eng.counters.rot_pops, g["rNodeCount"]))
+    assert 0.98 * g["rNodeCount"] <= eng.counters.rot_pops <= 1.25 * g["rNodeCount"], (eng.counters.rot_pops, g["rNodeCount"])
+    eng.registration.close()
+
+
 def test_e2e_skull_sub_reference_order(pkg):
     """BASELINE configs[2] pinned to the reference: the real GoICP::Register (src/goicp/jly_goicp.cpp:569-585) on the
     skull scan (98 359-point target, the DT over all of it) and every 10th point of the known-motion source

@@ -206,6 +206,23 @@ def test_e2e_spanner_sparse(oracle_mod):
     _check_e2e_sub(oracle_mod, "spanner_sparse", np.ascontiguousarray(cloud("spanner_target")[::8]), cloud("spanner_source", 50))
 
 
+@pytest.mark.parametrize("seed", [1, 3])
+def test_e2e_tiny_proven_optimum(oracle_mod, seed):
+    """The oracle on a CONVERGED search (no early exit): conftest.tiny_problem against the reference's own Register
+    (tests/golden/e2e_tiny<seed>.json: 1 609 / 1 201 rotation nodes, 177 k / 108 k translation nodes) -- same optimum, node counts within 0.5 % / 1 %."""
+    from conftest import tiny_problem
+    tgt, src = tiny_problem(seed)
+    g = golden("e2e_tiny%d" % seed)
+    assert g["sse"] > g["sse_threshold"]
+    dt = oracle_mod.DistanceTransform(tgt, 300, 2.0)
+    assert dt.scale == g["dt_scale"]
+    r = oracle_mod.register(dt, tgt, src, g["mse_threshold"])
+    assert abs(r["sse"] - g["sse"]) <= 1e-5 * g["sse"]
+    assert rot_angle(r["R"], np.array(g["R"]).reshape(3, 3)) <= 1e-5 and np.linalg.norm(r["t"] - np.array(g["t"])) <= 1e-5
+    assert abs(r["rot_pops"] - g["rNodeCount"]) <= max(1, 0.005 * g["rNodeCount"])
+    assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]
+
+
 def test_inner_bnb_spanner(oracle_mod):
     """The reference's InnerBnB on the spanner DT (V = 300 over the 150 000 noisy target points), every 50th source
     point: single expansions (min ub + arg-min child) and full searches, as test_inner_bnb_* do on the bunny."""

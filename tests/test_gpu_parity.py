@@ -567,6 +567,28 @@ def test_e2e_tiny_proven_optimum_reference_order(pkg, seed):
     eng.registration.close()
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_ranks_prove_the_reference_optimum(pkg, world):
+    """SURVEY 8(e)'s invariant on a CONVERGED search: conftest.small_problem(6) (the reference's Register proves the optimum in 7 403 rotation
+    nodes, tests/golden/e2e_small6.json) sharded over 2 / 4 / 8 ranks (host threads on this GPU, the library's protocol with its default step
+    ramp): every rank ends with the reference's optimum (SSE 1e-5, pose 1e-5), the ranks' rotation nodes add up to the reference's count within
+    10 % (a rank's share of the frontier is expanded in its own order; measured 7 431 / 7 477 / 7 559 against 7 403), no rank fails."""
+    from conftest import small_problem
+    from cuda_go_icp_amd import sharded
+    tgt, src, _, _ = small_problem(6)
+    g = golden("e2e_small6")
+    engines = [pkg.FastGoICP(tgt, src, g["mse_threshold"]) for _ in range(world)]
+    stats = sharded.run_thread_ranks(engines, rot_pops_per_step=8, ramp_to=32)
+    assert all(s["status"] == 0 and s["failed_rank"] == -1 for s in stats)
+    rots = sum(e.counters.rot_pops for e in engines)
+    print("sharded small6, %d ranks: rotation nodes of all ranks %d (reference %d), steps %d, donations %d" % (world, rots, g["rNodeCount"], stats[0]["steps"], stats[0]["donations"]))
+    for e in engines:
+        assert abs(float(e.get_best_error()) - g["sse"]) <= 1e-5 * g["sse"]
+        assert rot_angle(e.optR, np.array(g["R"])) <= 1e-5 and np.linalg.norm(e.optT - np.array(g["t"])) <= 1e-5
+        e.registration.close()
+    assert 0.98 * g["rNodeCount"] <= rots <= 1.10 * g["rNodeCount"]
+
+
 def test_e2e_skull_sub_reference_order(pkg):
     """BASELINE configs[2] pinned to the reference: the real GoICP::Register (src/goicp/jly_goicp.cpp:569-585) on the
     skull scan (98 359-point target, the DT over all of it) and every 10th point of the known-motion source

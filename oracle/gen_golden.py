@@ -15,6 +15,7 @@ usage: python oracle/gen_golden.py [--skip-full]     (full bunny e2e takes ~10 m
                                                       e2e_skull_sub.json, e2e_spanner_sub.json, e2e_spanner_sparse.json, inner_bnb_spanner.json; ~1 min)
 """
 import argparse
+import json
 import os
 import subprocess
 import sys
@@ -126,6 +127,23 @@ def sub_configs(h, tmp):
     if any(rc):
         sys.exit("harness failed: %r" % rc)
     os.replace(os.path.join(units_dir, "inner_bnb.json"), os.path.join(OUT, "inner_bnb_spanner.json"))
+    for name in ("dt_lookup", "nn", "icp_iter", "icp_dt_score"):          # the other unit fixtures of the same harness run: a second data set, a 3-level hierarchy
+        os.replace(os.path.join(units_dir, name + ".json"), os.path.join(OUT, name + "_spanner.json"))
+    # ... and the same on the skull scan (98 359 target points, every 10th source point); its DT samples are thinned to 512 + 512 (the spanner file carries a full set)
+    units_sk = os.path.join(tmp, "units_skull")
+    os.makedirs(units_sk, exist_ok=True)
+    subprocess.check_call([h, "units", units_sk, sk_t, sk_s, "10"], stdout=subprocess.DEVNULL)
+    for name in ("nn", "icp_iter", "icp_dt_score", "inner_bnb"):
+        os.replace(os.path.join(units_sk, name + ".json"), os.path.join(OUT, name + "_skull.json"))
+    with open(os.path.join(units_sk, "dt_lookup.json")) as f:
+        gl = json.load(f)
+    thin = {k: gl[k] for k in ("Nm", "SIZE", "scale", "xmin", "ymin", "zmin")}
+    for pts, vals in (("query", "distance"), ("voxel", "voxel_distance")):
+        sel = np.linspace(0, len(gl[vals]) - 1, 512).astype(int)
+        thin[pts] = [x for i in sel for x in gl[pts][3 * i:3 * i + 3]]
+        thin[vals] = [gl[vals][i] for i in sel]
+    with open(os.path.join(OUT, "dt_lookup_skull.json"), "w") as f:
+        json.dump(thin, f)
     print("sub-config fixtures written to", OUT)
 
 

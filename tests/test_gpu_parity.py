@@ -655,11 +655,69 @@ def test_e2e_spanner_sparse_wide(pkg):
     eng.registration.close()
 
 
-def test_golden_inner_bnb_spanner(pkg):
-    """The reference's InnerBnB on the spanner DT (tests/golden/inner_bnb_spanner.json): single expansions rel 1e-4 +
+def _second_data_set(tag):
+    if tag == "spanner":
+        return cloud("spanner_target"), cloud("spanner_source", 50)
+    from conftest import skull_problem
+    target, source, _, _ = skull_problem()
+    return target, np.ascontiguousarray(source[::10])
+
+
+@pytest.mark.parametrize("tag", ["spanner", "skull"])
+def test_reference_units_on_other_data_sets(pkg, oracle_mod, tag):
+    """The other BASELINE data sets and a THREE-level box hierarchy against the reference's own values (oracle/gen_golden.py --sub-configs -> the
+    harness's `units` on the noisy spanner, 150 000 target points, and on the skull scan, 98 359: tests/golden/{dt_lookup,nn,icp_iter,icp_dt_score}_<tag>.json):
+      * geometry of the distance transform bit-exact, 4 096 DT3D::Distance samples <= 0.35 voxel (jly_3ddt.cpp:981-1026);
+      * 4 096 nearest-neighbour squared distances of the reference's nanoflann tree BIT-EQUAL through the K = 3 hierarchy
+        (nanoflann_goicp.hpp:1137-1184; until now K = 3 was held to brute force only);
+      * ICP3D::Run trajectories with 1 / 2 / 10 forced iterations and to convergence from two start poses (jly_icp3d.hpp:181-295);
+      * the DT-scored error of a pose (jly_goicp.cpp:93-132)."""
+    tgt, src = _second_data_set(tag)
+    reg = pkg.Registration(tgt, src, 1e-3, trans_batch=1, wide_children=0)
+    g = golden("dt_lookup_" + tag)
+    V, scale, origin = reg.dt_info()
+    assert V == g["SIZE"] and scale == g["scale"] and origin == (g["xmin"], g["ymin"], g["zmin"])
+    v = np.array(g["voxel"]).reshape(-1, 3)
+    ref = np.array(g["voxel_distance"], dtype=np.float32)
+    mine = reg.dt_download()[v[:, 2], v[:, 1], v[:, 0]]
+    vox = 1.0 / g["scale"]
+    assert np.all(mine <= ref + 1e-7) and np.max(ref - mine) <= 0.35 * vox
+    g = golden("nn_" + tag)
+    q = np.array(g["query"], np.float32).reshape(-1, 3)
+    idx, d2 = reg.nn_query(q)
+    assert np.array_equal(d2, np.array(g["dist_sq"], np.float32))
+    assert np.mean(idx == np.array(g["index"])) > 0.999
+    g = golden("icp_iter_" + tag)
+    assert g["Nd"] == len(src)
+    # Tolerances: 1e-4 for 1 and 2 iterations; 2e-3 on the pose and on the error from 10 on (SURVEY 8c's e2e bar).  The reference accumulates the
+    # means and the 3 x 3 covariance of ~3 000 correspondences SEQUENTIALLY IN FLOAT (jly_icp3d.hpp:243-267: ~1e-5 relative of rounding noise that
+    # the oracle's restatement reproduces to 1e-6 and a parallel sum cannot).  Measured, HIP against oracle along the skull's trajectories
+    # (tools/icp_parity_probe.py): 7e-7 after one iteration, 6e-5 after two; from the first start pose it stays there (1e-5 at ten); from the
+    # second it is amplified while the cloud moves fastest -- 4e-4 at five iterations, 1.1e-3 at seven, 6e-4 at ten (error 60.28 against 60.38)
+    # -- and contracts again as both converge to the same fixed point: 9e-5 at twenty, 5e-6 at forty.  The bunny's fixture holds 1e-4 at ten.
+    for c in g["cases"]:
+        icp = pkg.IterativeClosestPoint3D(reg, c["max_iter"], c["err_diff"], c["R0"], c["t0"])
+        err, R, t = icp.run()
+        tol = 1e-4 if c["max_iter"] <= 2 else 2e-3
+        dR, dt_ = np.abs(R.ravel() - np.array(c["R"])).max(), np.abs(t - np.array(c["t"])).max()
+        print("icp %s max_iter %5d: max|dR| %.2e max|dt| %.2e err %.6g (reference %.6g)" % (tag, c["max_iter"], dR, dt_, err, c["err"]))
+        assert dR <= tol and dt_ <= tol, (c["max_iter"], dR, dt_)
+        assert abs(err - c["err"]) <= (1e-3 if c["max_iter"] <= 2 else 2e-3) * c["err"]
+        if c["max_iter"] <= 10:
+            assert icp.iters == c["max_iter"]
+    g = golden("icp_dt_score_" + tag)
+    sse = reg.compute_sse_error(np.array(g["R"]), np.array(g["t"]))
+    assert abs(sse - g["dt_sse"]) <= 1e-4 * max(g["dt_sse"], 1e-3)
+    reg.close()
+
+
+@pytest.mark.parametrize("tag", ["spanner", "skull"])
+def test_golden_inner_bnb_other_data_sets(pkg, tag):
+    """The reference's InnerBnB on the spanner DT and on the skull DT (tests/golden/inner_bnb_<tag>.json): single expansions rel 1e-4 +
     arg-min child, full searches in the reference visit order value rel 1e-3, pops within 1 %."""
-    g = golden("inner_bnb_spanner")
-    reg = pkg.Registration(cloud("spanner_target"), cloud("spanner_source", 50), 1e-3, trans_batch=1, wide_children=0)
+    g = golden("inner_bnb_" + tag)
+    tgt, src = _second_data_set(tag)
+    reg = pkg.Registration(tgt, src, 1e-3, trans_batch=1, wide_children=0)
     for case in g["cases"]:
         R = np.array(case["R"], np.float32)
         for s in case["single"]:

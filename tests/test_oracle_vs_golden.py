@@ -223,13 +223,53 @@ def test_e2e_tiny_proven_optimum(oracle_mod, seed):
     assert abs(r["trans_pops"] - g["tNodeCount"]) <= 0.01 * g["tNodeCount"]
 
 
-def test_inner_bnb_spanner(oracle_mod):
-    """The reference's InnerBnB on the spanner DT (V = 300 over the 150 000 noisy target points), every 50th source
-    point: single expansions (min ub + arg-min child) and full searches, as test_inner_bnb_* do on the bunny."""
-    g = golden("inner_bnb_spanner")
-    data = cloud("spanner_source", 50)
+def _second_data_set(tag):
+    """(target, strided source) of the unit fixtures *_spanner.json / *_skull.json (oracle/gen_golden.py --sub-configs)."""
+    if tag == "spanner":
+        return cloud("spanner_target"), cloud("spanner_source", 50)
+    from conftest import skull_problem
+    target, source, _, _ = skull_problem()
+    return target, np.ascontiguousarray(source[::10])
+
+
+@pytest.mark.parametrize("tag", ["spanner", "skull"])
+def test_reference_units_on_other_data_sets(oracle_mod, tag):
+    """The oracle against the reference's unit fixtures on the other BASELINE data sets (the noisy spanner: 150 000 target points, every 50th
+    source point; the skull scan: 98 359 target points, every 10th point of the known-motion source): DT3D::Distance samples, nanoflann
+    nearest neighbours, ICP3D::Run trajectories, the DT-scored error."""
+    tgt, src = _second_data_set(tag)
+    dt = oracle_mod.DistanceTransform(tgt, 300, 2.0)
+    g = golden("dt_lookup_" + tag)
+    assert dt.scale == g["scale"] and dt.origin == (g["xmin"], g["ymin"], g["zmin"])
+    q = np.array(g["query"]).reshape(-1, 3)
+    ref = np.array(g["distance"], dtype=np.float32)
+    mine = dt.distance(q)
+    vox = 1.0 / g["scale"]
+    assert np.all(mine <= ref + 1e-6) and np.max(ref - mine) <= 0.35 * vox and np.mean(mine == ref) > 0.999
+    g = golden("nn_" + tag)
+    kd = oracle_mod.KdTree(tgt)
+    idx, d2 = kd.nn(np.array(g["query"], dtype=np.float32).reshape(-1, 3))
+    assert np.array_equal(d2, np.array(g["dist_sq"], dtype=np.float32)) and np.mean(idx == np.array(g["index"])) > 0.999
+    g = golden("icp_iter_" + tag)
+    for c in g["cases"]:
+        err, R, t, it = kd.icp_run(src, c["R0"], c["t0"], c["max_iter"], c["err_diff"])
+        tol = 1e-4 if c["max_iter"] <= 10 else 1e-3
+        assert np.abs(R.ravel() - np.array(c["R"])).max() <= tol and np.abs(t - np.array(c["t"])).max() <= tol
+        assert abs(err - c["err"]) <= 1e-3 * c["err"]
+    g = golden("icp_dt_score_" + tag)
+    sse = oracle_mod.dt_sse(dt, src, np.array(g["R"]).reshape(3, 3), g["t"])
+    assert abs(sse - g["dt_sse"]) <= 1e-4 * max(g["dt_sse"], 1e-3)
+
+
+@pytest.mark.parametrize("tag", ["spanner", "skull"])
+def test_inner_bnb_other_data_sets(oracle_mod, tag):
+    """The reference's InnerBnB on the spanner DT (V = 300 over the 150 000 noisy target points, every 50th source point) and on the skull DT
+    (98 359 target points, every 10th source point): single expansions (min ub + arg-min child) and full searches, as test_inner_bnb_* do on
+    the bunny."""
+    g = golden("inner_bnb_" + tag)
+    tgt, data = _second_data_set(tag)
     assert len(data) == g["Nd"]
-    dt = oracle_mod.DistanceTransform(cloud("spanner_target"), 300, 2.0)
+    dt = oracle_mod.DistanceTransform(tgt, 300, 2.0)
     _, rho = oracle_mod.rot_radii(data)
     n = 0
     for case in g["cases"]:

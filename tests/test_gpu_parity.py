@@ -921,6 +921,35 @@ def test_trimmed_e2e_vs_oracle(pkg, oracle_mod, oracle_dt_bunny, bunny_model, bu
     assert eng.get_best_error() < eng.registration.params.mse_threshold * int(len(bunny_data10) * 0.9) * 1.0001
 
 
+def test_trimmed_tiny_proven_optimum_vs_oracle(pkg, oracle_mod):
+    """Trimming (GoICP::trimFraction, jly_goicp.cpp:201,293-315; the reference hard-wires 0) on a CONVERGED search: conftest.tiny_problem(1) at
+    trim_fraction 0.1 (the 54 best of 60 points), mse 4e-3 (SSEThresh 0.216 under the trimmed optimum's 0.247: 2.3 k rotation / 0.27 M translation nodes) -- the oracle's trimmed registration (seconds of CPU, run here) against the engine in
+    the reference visit order: same optimum, rotation nodes within 0.5 %, translation nodes within 1 % (measured: 2 313 = 2 313 and 270 629 =
+    270 629); the default search an optimum at least as good, within SSEThresh of it."""
+    from conftest import tiny_problem
+    tgt, src = tiny_problem(1)
+    dt = oracle_mod.DistanceTransform(tgt, 300, 2.0)
+    o = oracle_mod.register(dt, tgt, src, 4e-3, trim_fraction=0.1)
+    eng = pkg.FastGoICP(tgt, src, 4e-3, trim_fraction=0.1, trans_batch=1, wide_children=0)
+    eng.run()
+    c = eng.counters
+    sse = float(eng.get_best_error())
+    print("trimmed tiny1: sse %.7g (oracle %.7g) rotation nodes %d (oracle %d) translation nodes %d (oracle %d) rot_error %.2e" % (
+        sse, o["sse"], c.rot_pops, o["rot_pops"], c.trans_pops, o["trans_pops"], rot_angle(eng.optR, o["R"])))
+    assert o["rot_pops"] > 500 and o["sse"] > eng.sse_threshold                # converged, not an early exit
+    assert abs(sse - o["sse"]) <= 1e-4 * o["sse"] and rot_angle(eng.optR, o["R"]) <= 1e-4 and np.linalg.norm(eng.optT - o["t"]) <= 1e-4
+    assert abs(c.rot_pops - o["rot_pops"]) <= max(2, 0.005 * o["rot_pops"]) and abs(c.trans_pops - o["trans_pops"]) <= 0.01 * o["trans_pops"]
+    eng.registration.close()
+    # the default (widened) search: Go-ICP guarantees the error to within SSEThresh, not the pose -- another visit order may end in another optimum
+    # inside that band (measured: 0.2430613, the optimum the oracle itself finds at mse 3.5e-3, against the strict order's 0.2468403)
+    eng = pkg.FastGoICP(tgt, src, 4e-3, trim_fraction=0.1)
+    eng.run()
+    w = float(eng.get_best_error())
+    print("trimmed tiny1, default mode: sse %.7g" % w)
+    assert w <= o["sse"] * (1 + 1e-4) and o["sse"] - w <= eng.sse_threshold
+    eng.registration.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # BASELINE configs[0]: plain ICP (modes 0-2), step API, bunny-scale clouds
 # ----------------------------------------------------------------------------------------------

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--quick", action="store_true", help="skip the 6.7-second prove-the-optimum workload")
     ap.add_argument("--md", default="", help="also write the table as markdown to this file")
+    ap.add_argument("--only", default="", help="semicolon-separated variant names to run (default: all)")
+    ap.add_argument("--workloads", default="", help="comma-separated indices of the workloads to run (default: all)")
     args = ap.parse_args()
     from __graft_entry__ import _pkg
     pkg = _pkg()
@@ -50,8 +52,13 @@ def main():
                 ("ramp 8->64", dict(rot_pops_per_step=8, ramp_to=64)),
                 ("ramp 8->64, no rebalancing", dict(rot_pops_per_step=8, ramp_to=64, rebalance=False)),
                 ("ramp 8->64, stale exchange", dict(rot_pops_per_step=8, ramp_to=64, stale=True)),
-                ("ramp 8->32", dict(rot_pops_per_step=8, ramp_to=32))]
+                ("ramp 8->32", dict(rot_pops_per_step=8, ramp_to=32)),
+                ("ramp 8->16", dict(rot_pops_per_step=8, ramp_to=16))]
+    if args.only:
+        variants = [v for v in variants if v[0] in args.only.split(";")]
     worlds = [int(w) for w in args.worlds.split(",")]
+    if args.workloads:
+        workloads = [workloads[int(i)] for i in args.workloads.split(",")]
     out = {"tool": "tools/shard_inflation.py", "ranks_are": "host threads over goicp_thread_comm_create on ONE GPU (protocol = csrc/shard.cpp, as over RCCL)", "workloads": []}
     rows_md = []
     for name, tgt, src, mse in workloads:

@@ -158,6 +158,10 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
 	{ const char* e = std::getenv("GOICP_TILE_CONCURRENT"); if (e) tile_concurrent_ = std::atoi(e) != 0; }     // A/B only (tools/tile_deep.py)
+	lanes_ = p_.lanes; lane_min_searches_ = std::max(2, p_.lane_min_searches);
+	{ const char* e = std::getenv("GOICP_LANES"); if (e) lanes_ = std::atoi(e); }                                  // tuning only (tools/lanes_probe.py)
+	{ const char* e = std::getenv("GOICP_LANE_MIN"); if (e) lane_min_searches_ = std::max(2, std::atoi(e)); }
+	{ const char* e = std::getenv("GOICP_LANE_MIN_WORK"); if (e) lane_min_work_ = std::atof(e); }
 
 	h_target_.assign(target, target + 3 * M);
 	if (!(p_.trim_fraction >= 0.f) || p_.trim_fraction >= 1.f) throw std::invalid_argument("goicp: trim_fraction must be in [0,1)");
@@ -464,10 +468,10 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			HIPCHK(hipMalloc(&d_qinit_, sizeof(QInit) * kFlowSearches));
 			std::memset(h_qinit_, 0, sizeof(QInit) * kFlowSearches);
 		}
-		std::memset(h_qsearch_, 0, sizeof(QSearch) * cap_qsearch_);
-		HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyHostToDevice, stream_));
-		HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * cap_qsearch_, hipMemcpyDeviceToHost, stream_));
-		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		std::memset(ql_[0].h_search, 0, sizeof(QSearch) * ql_[0].cap);
+		HIPCHK(hipMemcpyAsync(ql_[0].d_search, ql_[0].h_search, sizeof(QSearch) * ql_[0].cap, hipMemcpyHostToDevice, stream_));
+		HIPCHK(hipMemcpyAsync(ql_[0].h_search, ql_[0].d_search, sizeof(QSearch) * ql_[0].cap, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(ql_[0].h_ctl, ql_[0].d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
 		HIPCHK(hipStreamSynchronize(stream_));
 		// ... and one dummy search that stops at its root (incumbent 0): the first launch of each queue kernel loads its
 		// code object, which belongs to engine creation, not to the first registration
@@ -484,7 +488,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			// read-back of the dummy search above does not trigger it, neither does the copy made before any kernel ran) -- it belongs to
 			// engine creation, not to the first registration (full bunny: first run 43 -> 34 ms)
 			const double tw = now_ms();
-			for (size_t n = 1; n <= cap_qsearch_; n *= 2) HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * n, hipMemcpyDeviceToHost, stream_));
+			for (size_t n = 1; n <= ql_[0].cap; n *= 2) HIPCHK(hipMemcpyAsync(ql_[0].h_search, ql_[0].d_search, sizeof(QSearch) * n, hipMemcpyDeviceToHost, stream_));
 			HIPCHK(hipStreamSynchronize(stream_));
 			if (p_.verbose) std::fprintf(stderr, "[goicp] create: read-back warm-up %.2f ms\n", now_ms() - tw);
 		}
@@ -497,15 +501,15 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 			std::memcpy(h_rots_[0].r, I9, sizeof(I9));
 			HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * (kFlowSearches / 2), hipMemcpyHostToDevice, stream_));
 			HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * kFlowSearches, hipMemcpyHostToDevice, stream_));
-			HIPCHK(launch_bnb_init_list(d_qsearch_, d_qnodes_, d_qinit_, 1, qp, stream_));
+			HIPCHK(launch_bnb_init_list(ql_[0].d_search, ql_[0].d_nodes, d_qinit_, 1, qp, stream_));
 			for (int r = 0; r < 3; r++) {
-				HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, kFlowSearches, qp, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));
-				HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0], &d_qctl_->chunks,
-				                           kFlowSearches * qp.K, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+				HIPCHK(launch_bnb_queue(ql_[0].d_search, ql_[0].d_nodes, kFlowSearches, qp, ql_[0].d_parents[q_parity_ ^ 1], ql_[0].d_parents[q_parity_], ql_[0].d_ub, ql_[0].d_lb, ql_[0].d_scratch, ql_[0].d_ctl, q_parity_, stream_));
+				HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, ql_[0].d_parents[q_parity_], &ql_[0].d_ctl->n_groups[q_parity_], &ql_[0].d_ctl->work[q_parity_][0], &ql_[0].d_ctl->chunks,
+				                           kFlowSearches * qp.K, inliers_, ql_[0].d_scratch, ql_[0].d_ub, ql_[0].d_lb, stream_));
 				q_parity_ ^= 1;
 			}
-			HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
-			HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * kFlowSearches, hipMemcpyDeviceToHost, stream_));
+			HIPCHK(hipMemcpyAsync(ql_[0].h_ctl, ql_[0].d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+			HIPCHK(hipMemcpyAsync(ql_[0].h_search, ql_[0].d_search, sizeof(QSearch) * kFlowSearches, hipMemcpyDeviceToHost, stream_));
 			HIPCHK(hipStreamSynchronize(stream_));
 			flow_reset();
 			HIPCHK(hipStreamSynchronize(stream_));
@@ -542,14 +546,8 @@ void Engine::release()
 	if (stream_ && hipGetDevice(&prev) == hipSuccess && prev != dev_) hipSetDevice(dev_); else prev = -1;
 	if (stream_) hipStreamSynchronize(stream_);
 	hipFree(d_opscratch_); d_opscratch_ = nullptr; cap_opscratch_ = 0;
-	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
-	hipFree(qsort_.keys); hipFree(qsort_.order); hipFree(qsort_.hist); hipFree(const_cast<float4*>(qsort_.cen)); qsort_ = QSort{};
-	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_); hipFree(d_qctl_); hipHostFree(h_qctl_);
-	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
-	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
+	for (QLane& L : ql_) free_lane(L);
 	hipFree(d_qinit_); hipHostFree(h_qinit_); d_qinit_ = nullptr; h_qinit_ = nullptr;
-	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr; d_qpsearch_[0] = d_qpsearch_[1] = nullptr;
-	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; d_qctl_ = nullptr; h_qctl_ = nullptr; cap_qsearch_ = 0;
 	hipFree(d_src_); hipFree(d_dt_); hipFree(d_overshoot_); hipFree(d_dt16_); d_dt16_ = nullptr;
 	hipFree(d_nn_ids_); d_nn_ids_ = nullptr;
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
@@ -568,7 +566,6 @@ void Engine::release()
 	if (ev0_) hipEventDestroy(ev0_);
 	if (ev1_) hipEventDestroy(ev1_);
 	if (stream2_) { hipStreamSynchronize(stream2_); hipStreamDestroy(stream2_); }
-	for (int k = 0; k < 2; k++) { if (ev_ctl_[k]) hipEventDestroy(ev_ctl_[k]); ev_ctl_[k] = nullptr; }
 	if (ev_fork_) hipEventDestroy(ev_fork_);
 	if (ev_join_) hipEventDestroy(ev_join_);
 	stream2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
@@ -1020,47 +1017,47 @@ void Engine::debug_queue_expand(const float R[9], int level, const float* parent
 	ensure_batch(1, 1);
 	std::memcpy(h_rots_[0].r, R, sizeof(float) * 9);
 	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9), hipMemcpyHostToDevice, stream_));
-	const bool twins = p_.twin_fusion && d_qpsearch_[0] != nullptr;
+	const bool twins = p_.twin_fusion && ql_[0].d_psearch[0] != nullptr;
 	// two searches whose queues hold exactly the given nodes (lower bound 0: all of them pass the stop rule against a huge incumbent and,
 	// n <= K, all are selected; the list keeps the queue order)
 	std::vector<QNode> nodes((size_t)n);
 	for (int i = 0; i < n; i++) nodes[(size_t)i] = QNode{parents4[4 * i], parents4[4 * i + 1], parents4[4 * i + 2], parents4[4 * i + 3], 0.f, 0.f};
 	for (int s = 0; s < 2; s++) {
-		QSearch& q = h_qsearch_[s];
+		QSearch& q = ql_[0].h_search[s];
 		std::memset(&q, 0, sizeof(q));
 		q.best = 1e30f; q.coeff = s ? rot_coeff(level) : 0.f; q.rot = 0; q.count = n; q.min_ub = INFINITY; q.twin = twins ? (s ^ 1) : -1;
-		HIPCHK(hipMemcpyAsync(d_qnodes_ + (size_t)s * kQueueCap, nodes.data(), sizeof(QNode) * (size_t)n, hipMemcpyHostToDevice, stream_));
+		HIPCHK(hipMemcpyAsync(ql_[0].d_nodes + (size_t)s * kQueueCap, nodes.data(), sizeof(QNode) * (size_t)n, hipMemcpyHostToDevice, stream_));
 	}
-	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * 2, hipMemcpyHostToDevice, stream_));
-	std::memset(h_qctl_, 0, sizeof(QCtl));
-	h_qctl_->tile_chunks = 1;
-	HIPCHK(hipMemcpyAsync(d_qctl_, h_qctl_, sizeof(QCtl), hipMemcpyHostToDevice, stream_));
+	HIPCHK(hipMemcpyAsync(ql_[0].d_search, ql_[0].h_search, sizeof(QSearch) * 2, hipMemcpyHostToDevice, stream_));
+	std::memset(ql_[0].h_ctl, 0, sizeof(QCtl));
+	ql_[0].h_ctl->tile_chunks = 1;
+	HIPCHK(hipMemcpyAsync(ql_[0].d_ctl, ql_[0].h_ctl, sizeof(QCtl), hipMemcpyHostToDevice, stream_));
 	QParams qp = queue_params();
 	qp.K = std::max(n, 1); qp.kmax = kQueueRoundPop; qp.tile_on = 0; qp.stale_widen = 0; qp.stale_compact = 0;
 	const int parity = 0, max_groups = 2 * n;
-	HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, 2, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, nullptr,
-	                        twins ? d_qpsearch_[parity] : nullptr));
-	HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
-	                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, nullptr));
-	HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
-	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * 2, hipMemcpyDeviceToHost, stream_));
+	HIPCHK(launch_bnb_queue(ql_[0].d_search, ql_[0].d_nodes, 2, qp, ql_[0].d_parents[parity ^ 1], ql_[0].d_parents[parity], ql_[0].d_ub, ql_[0].d_lb, ql_[0].d_scratch, ql_[0].d_ctl, parity, stream_, nullptr,
+	                        twins ? ql_[0].d_psearch[parity] : nullptr));
+	HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, ql_[0].d_parents[parity], &ql_[0].d_ctl->n_groups[parity], &ql_[0].d_ctl->work[parity][0], &ql_[0].d_ctl->chunks, max_groups,
+	                           inliers_, ql_[0].d_scratch, ql_[0].d_ub, ql_[0].d_lb, stream_, twins ? ql_[0].d_search : nullptr, twins ? ql_[0].d_psearch[parity] : nullptr, nullptr));
+	HIPCHK(hipMemcpyAsync(ql_[0].h_ctl, ql_[0].d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+	HIPCHK(hipMemcpyAsync(ql_[0].h_search, ql_[0].d_search, sizeof(QSearch) * 2, hipMemcpyDeviceToHost, stream_));
 	HIPCHK(hipStreamSynchronize(stream_));
-	if (h_qctl_->overflow || h_qctl_->n_groups[parity] != 2 * n || h_qsearch_[0].n_parents != n || h_qsearch_[1].n_parents != n)
+	if (ql_[0].h_ctl->overflow || ql_[0].h_ctl->n_groups[parity] != 2 * n || ql_[0].h_search[0].n_parents != n || ql_[0].h_search[1].n_parents != n)
 		throw std::logic_error("goicp: debug_queue_expand: the round did not list every node");
-	const int chunks = h_qctl_->chunks;
+	const int chunks = ql_[0].h_ctl->chunks;
 	info[0] = chunks; info[1] = twins ? 1 : 0;
 	std::vector<ParentRec> listed((size_t)2 * n);
-	HIPCHK(hipMemcpy(listed.data(), d_qparents_[parity], sizeof(ParentRec) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(listed.data(), ql_[0].d_parents[parity], sizeof(ParentRec) * 2 * (size_t)n, hipMemcpyDeviceToHost));
 	std::vector<float> ub((size_t)16 * n), lb((size_t)16 * n), part;
 	if (chunks > 1) {
 		part.resize((size_t)2 * n * chunks * 2 * kGroup);
-		HIPCHK(hipMemcpy(part.data(), d_qscratch_, sizeof(float) * part.size(), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(part.data(), ql_[0].d_scratch, sizeof(float) * part.size(), hipMemcpyDeviceToHost));
 	} else {
-		HIPCHK(hipMemcpy(ub.data(), d_qub_, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(lb.data(), d_qlb_, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(ub.data(), ql_[0].d_ub, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(lb.data(), ql_[0].d_lb, sizeof(float) * 16 * (size_t)n, hipMemcpyDeviceToHost));
 	}
 	for (int s = 0; s < 2; s++) {
-		const int off = h_qsearch_[s].parent_off;
+		const int off = ql_[0].h_search[s].parent_off;
 		float* ou = s ? ub1 : ub0; float* ol = s ? lb1 : lb0;
 		for (int e = 0; e < n; e++) {
 			const ParentRec& pr = listed[(size_t)off + e];
@@ -1136,32 +1133,46 @@ void Engine::ensure_stage(int k, size_t B)
 	st.cap = cap;
 }
 
-void Engine::ensure_queues(size_t nsearch)
+void Engine::free_lane(QLane& L)
 {
-	if (nsearch <= cap_qsearch_) return;
+	hipFree(L.d_search); hipHostFree(L.h_search); hipFree(L.d_nodes);
+	for (int k = 0; k < 2; k++) { hipFree(L.d_parents[k]); hipFree(L.d_psearch[k]); hipFree(L.tile.parents[k]); hipFree(L.tile.segs[k]); if (L.ev_ctl[k]) hipEventDestroy(L.ev_ctl[k]); }
+	hipFree(L.sort.keys); hipFree(L.sort.order); hipFree(L.sort.hist); hipFree(const_cast<float4*>(L.sort.cen));
+	hipFree(L.d_ub); hipFree(L.d_lb); hipFree(L.d_scratch); hipFree(L.d_ctl); hipHostFree(L.h_ctl);
+	hipFree(L.tile.ub); hipFree(L.tile.lb); hipFree(L.tile.scratch);
+	L = QLane{};          // the stream is the engine's (stream_ / stream2_), not the lane's to destroy
+}
+
+void Engine::ensure_queues(size_t nsearch) { ensure_lane(0, nsearch); }
+
+void Engine::ensure_lane(int li, size_t nsearch)
+{
+	QLane& L = ql_[li];
+	L.stream = li == 0 ? stream_ : stream2_;
+	if (nsearch <= L.cap) return;
 	// first use: room for a full round of the outer search (rot_batch parents x 8 children x {ub, lb} pass) -- growing in
 	// steps would re-allocate the 196 KB-per-search slabs several times in the first rounds
-	size_t cap = std::max<size_t>(cap_qsearch_, p_.wide_children ? (size_t)16 * (size_t)std::max(1, p_.rot_batch) : 16);
+	size_t cap = std::max<size_t>(L.cap, p_.wide_children ? (size_t)16 * (size_t)std::max(1, p_.rot_batch) : 16);
 	while (cap < nsearch) cap *= 2;
-	HIPCHK(hipStreamSynchronize(stream_));
-	hipFree(d_qsearch_); hipHostFree(h_qsearch_); hipFree(d_qnodes_); hipFree(d_qparents_[0]); hipFree(d_qparents_[1]); hipFree(d_qpsearch_[0]); hipFree(d_qpsearch_[1]);
-	hipFree(qsort_.keys); hipFree(qsort_.order); hipFree(qsort_.hist); hipFree(const_cast<float4*>(qsort_.cen)); qsort_ = QSort{};
-	hipFree(d_qub_); hipFree(d_qlb_); hipFree(d_qscratch_);
-	for (int k = 0; k < 2; k++) { hipFree(qtile_.parents[k]); hipFree(qtile_.segs[k]); }
-	hipFree(qtile_.ub); hipFree(qtile_.lb); hipFree(qtile_.scratch); qtile_ = QTile{};
-	d_qsearch_ = nullptr; h_qsearch_ = nullptr; d_qnodes_ = nullptr; d_qparents_[0] = d_qparents_[1] = nullptr; d_qpsearch_[0] = d_qpsearch_[1] = nullptr;
-	d_qub_ = d_qlb_ = d_qscratch_ = nullptr; cap_qsearch_ = 0;
+	HIPCHK(hipStreamSynchronize(L.stream));
+	hipFree(L.d_search); hipHostFree(L.h_search); hipFree(L.d_nodes); hipFree(L.d_parents[0]); hipFree(L.d_parents[1]); hipFree(L.d_psearch[0]); hipFree(L.d_psearch[1]);
+	hipFree(L.sort.keys); hipFree(L.sort.order); hipFree(L.sort.hist); hipFree(const_cast<float4*>(L.sort.cen)); L.sort = QSort{};
+	hipFree(L.d_ub); hipFree(L.d_lb); hipFree(L.d_scratch);
+	for (int k = 0; k < 2; k++) { hipFree(L.tile.parents[k]); hipFree(L.tile.segs[k]); }
+	hipFree(L.tile.ub); hipFree(L.tile.lb); hipFree(L.tile.scratch); L.tile = QTile{};
+	L.d_search = nullptr; L.h_search = nullptr; L.d_nodes = nullptr; L.d_parents[0] = L.d_parents[1] = nullptr; L.d_psearch[0] = L.d_psearch[1] = nullptr;
+	L.d_ub = L.d_lb = L.d_scratch = nullptr; L.cap = 0;
 	const size_t max_groups = cap * kQueueRoundPop;          // what the round's lists hold; QParams::kmax keeps (searches running) x (their steps) inside
-	q_list_cap_ = (int)max_groups;
+	L.list_cap = (int)max_groups;
 	// segments (<= 64 expansions of one search) of the tile list: every search contributes floor(n / 64) full ones and at most one partial
-	q_seg_cap_ = (int)(max_groups / 64 + cap);
-	HIPCHK(hipMalloc(&d_qsearch_, sizeof(QSearch) * cap));
-	HIPCHK(hipHostMalloc(&h_qsearch_, sizeof(QSearch) * cap));
-	HIPCHK(hipMalloc(&d_qnodes_, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
-	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qparents_[k], sizeof(ParentRec) * max_groups));
-	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&d_qpsearch_[k], sizeof(int) * max_groups));
-	HIPCHK(hipMalloc(&d_qub_, sizeof(float) * max_groups * kGroup));
-	HIPCHK(hipMalloc(&d_qlb_, sizeof(float) * max_groups * kGroup));
+	L.seg_cap = (int)(max_groups / 64 + cap);
+	HIPCHK(hipMalloc(&L.d_search, sizeof(QSearch) * cap));
+	HIPCHK(hipHostMalloc(&L.h_search, sizeof(QSearch) * cap));
+	HIPCHK(hipMalloc(&L.d_nodes, sizeof(QNode) * cap * kQueueCap));          // 196 KB per search; HBM is not the scarce resource here
+	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&L.d_parents[k], sizeof(ParentRec) * max_groups));
+	for (int k = 0; k < 2; k++) HIPCHK(hipMalloc(&L.d_psearch[k], sizeof(int) * max_groups));
+	HIPCHK(hipMalloc(&L.d_ub, sizeof(float) * max_groups * kGroup));
+	HIPCHK(hipMalloc(&L.d_lb, sizeof(float) * max_groups * kGroup));
 	// footprint-ordered items for the large rounds (lean grids, untrimmed, clouds of 4..16 chunks of 4 096 points).  Measured, registration in ms,
 	// chunk 2 048 | 3 072 | 4 096 | 6 144 | search order: bunny 34.4 | 33.1 | 33.8 | 34.1 | 36.8 (run-to-run +-0.6); bunny mse 1e-4 280 | 277 | 280 | 276 | 295;
 	// synthetic 40 k mse 3e-5 798 | 758 | 714 | 725 | 921; spanner 150 k mse 2e-5 223 | 212 | 206 | 201 | 195 -- above ~64 k points the unsorted
@@ -1176,37 +1187,36 @@ void Engine::ensure_queues(size_t nsearch)
 	if (p_.sort_items && bounds_uses_lean(bounds_dt()) && inliers_ >= (int)N_ && N_ >= 12288 && N_ <= 65536 && sort_chunks >= 4 && sort_chunks <= 16) {
 		float4* cen = nullptr;
 		HIPCHK(hipMalloc(&cen, sizeof(float4) * sort_chunks));
-		HIPCHK(launch_chunk_centroids(d_src_, (int)N_, kSortChunkPts, cen, stream_));
-		qsort_.cen = cen;
-		HIPCHK(hipMalloc(&qsort_.keys, sizeof(unsigned) * max_groups * sort_chunks));
-		HIPCHK(hipMalloc(&qsort_.order, sizeof(unsigned) * max_groups * sort_chunks));
-		HIPCHK(hipMalloc(&qsort_.hist, qsort_hist_bytes()));
-		HIPCHK(hipMemsetAsync(qsort_.hist, 0, qsort_hist_bytes(), stream_));     // kept zero between uses by the kernels themselves
-		qsort_.chunk_pts = kSortChunkPts; qsort_.chunks = sort_chunks; qsort_.min_groups = 256;
-		if (const char* e = std::getenv("GOICP_SORT_MIN_GROUPS")) { const int v = std::atoi(e); if (v > 0) qsort_.min_groups = v; }     // tuning only (tools/tune_e2e.py); the default is the measured optimum                    // rounds from this many expansions.  Round 3 (512 | 1024 | 2048 | 4096): 35.0 | 34.5 | 33.6 | 37.3 ms.  Re-swept in round 4 with the
+		HIPCHK(launch_chunk_centroids(d_src_, (int)N_, kSortChunkPts, cen, L.stream));
+		L.sort.cen = cen;
+		HIPCHK(hipMalloc(&L.sort.keys, sizeof(unsigned) * max_groups * sort_chunks));
+		HIPCHK(hipMalloc(&L.sort.order, sizeof(unsigned) * max_groups * sort_chunks));
+		HIPCHK(hipMalloc(&L.sort.hist, qsort_hist_bytes()));
+		HIPCHK(hipMemsetAsync(L.sort.hist, 0, qsort_hist_bytes(), L.stream));     // kept zero between uses by the kernels themselves
+		L.sort.chunk_pts = kSortChunkPts; L.sort.chunks = sort_chunks; L.sort.min_groups = 256;
+		if (const char* e = std::getenv("GOICP_SORT_MIN_GROUPS")) { const int v = std::atoi(e); if (v > 0) L.sort.min_groups = v; }     // tuning only (tools/tune_e2e.py); the default is the measured optimum                    // rounds from this many expansions.  Round 3 (512 | 1024 | 2048 | 4096): 35.0 | 34.5 | 33.6 | 37.3 ms.  Re-swept in round 4 with the
 		// twin lists and the 4 096-point chunks in place (tools/sort_threshold_probe.py, median of 7): 1 | 128 | 512 | 1024 | 2048 | 4096 | off = 33.8 | 33.3 | 33.5 | 33.6 | 34.4 | 36.6 | 36.3 ms;
 		// mse 1e-4 / 3e-5 (0.27 / 6.8 s) flat between 128, 256 and 2048 -- so round 1 of a large batch (230 roots x two passes) is sorted too
-		qsort_.shift = qsort_shift(dt_.V);           // 16-voxel cells (32-voxel cells: 35.1 ms)
+		L.sort.shift = qsort_shift(dt_.V);           // 16-voxel cells (32-voxel cells: 35.1 ms)
 	}
-	HIPCHK(hipMalloc(&d_qscratch_, sizeof(float) * bounds_queue_scratch_floats((int)max_groups, qsort_.order ? qsort_.chunks : 0)));
+	HIPCHK(hipMalloc(&L.d_scratch, sizeof(float) * bounds_queue_scratch_floats((int)max_groups, L.sort.order ? L.sort.chunks : 0)));
 	if (tiles_usable()) {
 		// the second expansion list of a round (LDS-staged DT tiles): same capacity as the direct list
 		for (int k = 0; k < 2; k++) {
-			HIPCHK(hipMalloc(&qtile_.parents[k], sizeof(ParentRec) * max_groups));
-			HIPCHK(hipMalloc(&qtile_.segs[k], sizeof(TileSeg) * q_seg_cap_));
+			HIPCHK(hipMalloc(&L.tile.parents[k], sizeof(ParentRec) * max_groups));
+			HIPCHK(hipMalloc(&L.tile.segs[k], sizeof(TileSeg) * L.seg_cap));
 		}
-		HIPCHK(hipMalloc(&qtile_.ub, sizeof(float) * max_groups * kGroup));
-		HIPCHK(hipMalloc(&qtile_.lb, sizeof(float) * max_groups * kGroup));
-		HIPCHK(hipMalloc(&qtile_.scratch, sizeof(float) * bounds_tile_queue_scratch_floats(q_seg_cap_)));
+		HIPCHK(hipMalloc(&L.tile.ub, sizeof(float) * max_groups * kGroup));
+		HIPCHK(hipMalloc(&L.tile.lb, sizeof(float) * max_groups * kGroup));
+		HIPCHK(hipMalloc(&L.tile.scratch, sizeof(float) * bounds_tile_queue_scratch_floats(L.seg_cap)));
 	}
-	if (!d_qctl_) {
-		HIPCHK(hipMalloc(&d_qctl_, sizeof(QCtl)));
-		HIPCHK(hipHostMalloc(&h_qctl_, sizeof(QCtl) * 2));
-		std::memset(h_qctl_, 0, sizeof(QCtl) * 2);
-		for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&ev_ctl_[k], hipEventDisableTiming));
-		{ const char* e = std::getenv("GOICP_QUEUE_AHEAD"); if (e) queue_ahead_ = std::atoi(e) != 0; }
+	if (!L.d_ctl) {
+		HIPCHK(hipMalloc(&L.d_ctl, sizeof(QCtl)));
+		HIPCHK(hipHostMalloc(&L.h_ctl, sizeof(QCtl) * 2));
+		std::memset(L.h_ctl, 0, sizeof(QCtl) * 2);
+		for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&L.ev_ctl[k], hipEventDisableTiming));
 	}
-	cap_qsearch_ = cap;
+	L.cap = cap;
 }
 
 // The inner searches with their queues on the device: a round = bnb_queue_kernel (digest the previous round's
@@ -1217,151 +1227,188 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	TraceRange tr("goicp:inner_bnb_rounds");
 	const size_t S = searches.size(), nrot = rots.size();
 	const int K = std::min(std::max(1, p_.trans_batch), kQueueRoundPop);
-	ensure_queues(S);
 	ensure_batch(1, nrot);
 	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
 	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * nrot, hipMemcpyHostToDevice, stream_));
-	for (size_t i = 0; i < S; i++) {
-		QSearch& q = h_qsearch_[i];
-		std::memset(&q, 0, sizeof(q));
-		q.best = searches[i]->best; q.coeff = searches[i]->coeff; q.rot = searches[i]->rot_slot;
-		q.twin = -1;
+	// Lanes: the searches of a batch are independent of each other (own queue, own incumbent; only the two passes of one rotation child --
+	// twins, same rotation slot -- share loads), so a large batch is cut in two by rotation slot and each half runs its own lock-step rounds
+	// on its own stream with its own lists and control block.  Same bounds, same stop and prune rules per search; what changes is that one
+	// lane's dependent launches (queue kernel -> sort -> bound evaluation, each draining before the next starts) run beside the other's.
+	// ... which pays when a round is throughput-bound (its kernels' drain tails are what the other lane fills) and costs when it is latency-bound
+	// (two half rounds take longer than one whole).  Measured (tools/lanes_probe.py, one lane -> two): rounds of 416 M point-expansions (bunny,
+	// mse 3e-5) 6.74 -> 5.67 s, 183 M (synthetic 40 k, mse 3e-5) 724 -> 659 ms, 90 M (bunny, mse 1e-4) 269 -> 264 ms, 39 M (3 k points, mse 3e-5)
+	// 1.10 -> 1.22 s, 20 M (the default bunny registration) 33.7 -> 34.2 ms.  So lanes = 0 (auto) cuts a batch in two when the PREVIOUS batch's
+	// mean round was at least lane_min_work_ point-expansions -- a count, not a time: the choice is deterministic
+	const bool lanes_wanted = lanes_ >= 2 || (lanes_ == 0 && last_round_work_ >= lane_min_work_);
+	const int nl = (lanes_wanted && S >= (size_t)lane_min_searches_ && stream2_) ? 2 : 1;
+	struct Run {
+		QLane* L = nullptr;
+		std::vector<int> idx;                 // lane slot -> index into `searches`
+		QParams qp{};
+		int parity = 0, chunk = 3, rounds_done = 0, last = 0;
+		long long round_cap = 0;
+		bool sort_round = false, tiles = false, twins = false, done = false;
+	} run[2];
+	if (nl == 1) { run[0].idx.resize(S); for (size_t i = 0; i < S; i++) run[0].idx[i] = (int)i; }
+	else for (size_t i = 0; i < S; i++) run[searches[i]->rot_slot & 1].idx.push_back((int)i);
+	if (nl == 2 && (run[0].idx.empty() || run[1].idx.empty())) throw std::logic_error("goicp: a lane without searches");
+	if (nl == 2) {            // lane 1 starts behind the rotation upload (and everything else queued on the engine's stream)
+		HIPCHK(hipEventRecord(ev_fork_, stream_));
+		HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
 	}
-	// the two searches of a rotation child (same rotation slot, one upper-bound pass with coeff 0, one lower-bound pass): each other's twin
-	if (p_.twin_fusion && d_qpsearch_[0]) {
-		std::vector<int> first(nrot, -1);
-		for (size_t i = 0; i < S; i++) {
-			const int r = searches[i]->rot_slot;
-			if (first[r] < 0) { first[r] = (int)i; continue; }
-			const int j = first[r];
-			if (j >= 0 && h_qsearch_[j].twin < 0 && (h_qsearch_[j].coeff == 0.f) != (h_qsearch_[i].coeff == 0.f)) { h_qsearch_[j].twin = (int)i; h_qsearch_[i].twin = j; }
+	for (int li = 0; li < nl; li++) {
+		Run& r = run[li];
+		const size_t Sl = r.idx.size();
+		ensure_lane(li, Sl);
+		QLane& L = ql_[li];
+		r.L = &L;
+		for (size_t i = 0; i < Sl; i++) {
+			const InnerSearch& src = *searches[(size_t)r.idx[i]];
+			QSearch& q = L.h_search[i];
+			std::memset(&q, 0, sizeof(q));
+			q.best = src.best; q.coeff = src.coeff; q.rot = src.rot_slot;
+			q.twin = -1;
 		}
+		// the two searches of a rotation child (same rotation slot, one upper-bound pass with coeff 0, one lower-bound pass): each other's twin
+		if (p_.twin_fusion && L.d_psearch[0]) {
+			std::vector<int> first(nrot, -1);
+			for (size_t i = 0; i < Sl; i++) {
+				const int rs = L.h_search[i].rot;
+				if (first[(size_t)rs] < 0) { first[(size_t)rs] = (int)i; continue; }
+				const int j = first[(size_t)rs];
+				if (L.h_search[j].twin < 0 && (L.h_search[j].coeff == 0.f) != (L.h_search[i].coeff == 0.f)) { L.h_search[j].twin = (int)i; L.h_search[i].twin = j; }
+			}
+		}
+		HIPCHK(hipMemcpyAsync(L.d_search, L.h_search, sizeof(QSearch) * Sl, hipMemcpyHostToDevice, L.stream));
+		r.qp = queue_params();
+		r.qp.list_cap = L.list_cap; r.qp.seg_cap = L.seg_cap;
+		r.qp.K = K;
+		r.qp.kmax = std::min(kQueueMaxPop, L.list_cap / (int)std::max<size_t>(Sl, 1));   // >= kQueueRoundPop: Sl <= the slots the lists were sized for
+		HIPCHK(launch_bnb_init(L.d_search, L.d_nodes, (int)Sl, r.qp, L.d_ctl, L.stream));
+		// the tile list: always on (lds_tiles 1), or -- the default -- only for the rounds that follow a read-back in which searches
+		// qualified (QCtl::tile_hint moved): shallow batches, i.e. every default registration, never pay for the extra launch
+		r.tiles = L.tile.ub != nullptr;
+		r.twins = p_.twin_fusion && L.d_psearch[0] != nullptr;
+		// footprint-ordered items: the sort is queued only for rounds that can reach sort.min_groups expansions -- the first rounds of a
+		// batch by what a search can list in them (1, 8, 64 .. nodes), later ones by what the last read-back saw
+		r.round_cap = (long long)Sl;
+		r.sort_round = L.sort.order != nullptr;
+		r.qp.tile_on = r.tiles && p_.lds_tiles == 1 ? 1 : 0;
+		L.tile_hint_seen = 0;
 	}
-	HIPCHK(hipMemcpyAsync(d_qsearch_, h_qsearch_, sizeof(QSearch) * S, hipMemcpyHostToDevice, stream_));
-	QParams qp = queue_params();
-	qp.K = K;
-	qp.kmax = std::min(kQueueMaxPop, q_list_cap_ / (int)std::max<size_t>(S, 1));   // >= kQueueRoundPop: S <= the slots the lists were sized for
-	HIPCHK(launch_bnb_init(d_qsearch_, d_qnodes_, (int)S, qp, d_qctl_, stream_));
-	int parity = 0, chunk = 3;
-	// the tile list: always on (lds_tiles 1), or -- the default -- only for the rounds that follow a read-back in which searches
-	// qualified (QCtl::tile_hint moved): shallow batches, i.e. every default registration, never pay for the extra launch
-	const bool tiles = qtile_.ub != nullptr;
-	const bool twins = p_.twin_fusion && d_qpsearch_[0] != nullptr;
-	// footprint-ordered items: the sort is queued only for rounds that can reach qsort_.min_groups expansions -- the first rounds of a
-	// batch by what a search can list in them (1, 8, 64 .. nodes), later ones by what the last read-back saw
-	long long round_cap = (long long)S;
-	bool sort_round = qsort_.order != nullptr;
-	int rounds_done = 0;
-	qp.tile_on = tiles && p_.lds_tiles == 1 ? 1 : 0;
-	tile_hint_seen_ = 0;
-	// One chunk of rounds: queue kernel + (sort) + bound evaluation(s) per round, then the control block's read-back into snapshot `slot`.
-	int last_of[2] = {0, 0};
-	auto submit = [&](int slot) {
+	// One chunk of rounds of a lane: queue kernel + (sort) + bound evaluation(s) per round, then the control block's read-back.
+	auto submit = [&](Run& r) {
 		const double t0 = now_ms();
-		int last = 0;
-		const int max_groups = (int)std::min<size_t>(S * (size_t)std::min(qp.kmax, 4 * qp.K), (size_t)q_list_cap_);   // most the round can list (the kernel widens a stale search's step up to x4)
-		for (int r = 0; r < chunk; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, (int)S, qp, d_qparents_[parity ^ 1], d_qparents_[parity], d_qub_, d_qlb_, d_qscratch_, d_qctl_, parity, stream_, tiles ? &qtile_ : nullptr,
-			                        twins ? d_qpsearch_[parity] : nullptr));
+		QLane& L = *r.L;
+		const size_t Sl = r.idx.size();
+		QParams& qp = r.qp;
+		const int max_groups = (int)std::min<size_t>(Sl * (size_t)std::min(qp.kmax, 4 * qp.K), (size_t)L.list_cap);   // most the round can list (the kernel widens a stale search's step up to x4)
+		for (int k = 0; k < r.chunk; k++) {
+			const int parity = r.parity;
+			HIPCHK(launch_bnb_queue(L.d_search, L.d_nodes, (int)Sl, qp, L.d_parents[parity ^ 1], L.d_parents[parity], L.d_ub, L.d_lb, L.d_scratch, L.d_ctl, parity, L.stream, r.tiles ? &L.tile : nullptr,
+			                        r.twins ? L.d_psearch[parity] : nullptr));
 			// The round's two lists are independent (own records, own bounds, own partial sums), so the tile list's evaluation CAN be forked onto a
 			// second stream right behind the queue kernel and run beside the direct list's.  Built and measured (EXPERIMENTS R4.8): slower -- bunny
 			// mse 3e-5 6.73 -> 7.40 s, bunny/10 1.09 -> 1.14 s, identical results -- the VALU-bound tile kernel (32 KB of LDS per workgroup) and the
-			// gather kernel (122 VGPRs) take each other's occupancy; opt-in for A/B only
-			const bool fork_tiles = qp.tile_on && tile_concurrent_;
+			// gather kernel (122 VGPRs) take each other's occupancy; opt-in for A/B only (single-lane batches)
+			const bool fork_tiles = qp.tile_on && tile_concurrent_ && nl == 1;
 			if (fork_tiles) {
-				HIPCHK(hipEventRecord(ev_fork_, stream_));
+				HIPCHK(hipEventRecord(ev_fork_, L.stream));
 				HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-				HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream2_));
+				HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, L.tile, L.d_ctl, parity, stream2_));
 				HIPCHK(hipEventRecord(ev_join_, stream2_));
 				tile_rounds_++;
 			}
-			const bool sorted = sort_round && std::min<long long>(round_cap, max_groups) >= qsort_.min_groups;
-			if (sorted) HIPCHK(launch_queue_sort(d_qparents_[parity], d_rots_, &d_qctl_->n_groups[parity], max_groups, qsort_, bounds_dt(), stream_));
-			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[parity], &d_qctl_->n_groups[parity], &d_qctl_->work[parity][0], &d_qctl_->chunks, max_groups,
-			                           inliers_, d_qscratch_, d_qub_, d_qlb_, stream_, twins ? d_qsearch_ : nullptr, twins ? d_qpsearch_[parity] : nullptr, sorted ? &qsort_ : nullptr));
-			if (round_cap < (1ll << 40)) round_cap *= 8;
-			rounds_done++;
-			if (fork_tiles) HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
-			else if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, qtile_, d_qctl_, parity, stream_)); tile_rounds_++; }
-			last = parity;
-			parity ^= 1;
+			const bool sorted = r.sort_round && std::min<long long>(r.round_cap, max_groups) >= L.sort.min_groups;
+			if (sorted) HIPCHK(launch_queue_sort(L.d_parents[parity], d_rots_, &L.d_ctl->n_groups[parity], max_groups, L.sort, bounds_dt(), L.stream));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, L.d_parents[parity], &L.d_ctl->n_groups[parity], &L.d_ctl->work[parity][0], &L.d_ctl->chunks, max_groups,
+			                           inliers_, L.d_scratch, L.d_ub, L.d_lb, L.stream, r.twins ? L.d_search : nullptr, r.twins ? L.d_psearch[parity] : nullptr, sorted ? &L.sort : nullptr));
+			if (r.round_cap < (1ll << 40)) r.round_cap *= 8;
+			r.rounds_done++;
+			if (fork_tiles) HIPCHK(hipStreamWaitEvent(L.stream, ev_join_, 0));
+			else if (qp.tile_on) { HIPCHK(launch_bounds_tile_queue(d_src_, (int)N_, dt_, d_rots_, L.tile, L.d_ctl, parity, L.stream)); tile_rounds_++; }
+			r.last = parity;
+			r.parity ^= 1;
 			cnt_.bounds_launches++;
 			queue_rounds_++;
 		}
-		HIPCHK(hipMemcpyAsync(h_qctl_ + slot, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
-		HIPCHK(hipEventRecord(ev_ctl_[slot], stream_));
-		last_of[slot] = last;
+		HIPCHK(hipMemcpyAsync(L.h_ctl, L.d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, L.stream));
+		HIPCHK(hipEventRecord(L.ev_ctl[0], L.stream));
 		t_submit_ += now_ms() - t0;
 	};
 	// fold a chunk's read-back into the parameters of the chunks still to be queued
-	auto adapt = [&](const QCtl& c, int last) {
-		if (tiles && p_.lds_tiles == 2) { qp.tile_on = c.tile_hint != tile_hint_seen_ ? 1 : 0; tile_hint_seen_ = c.tile_hint; }
+	auto adapt = [&](Run& r, const QCtl& c) {
+		QLane& L = *r.L;
+		QParams& qp = r.qp;
+		if (r.tiles && p_.lds_tiles == 2) { qp.tile_on = c.tile_hint != L.tile_hint_seen ? 1 : 0; L.tile_hint_seen = c.tile_hint; }
 		// (later rounds of a batch are narrow -- their expansions lie close together whatever the order -- and in long registrations the three
 		// extra launches per round are not free on the host side: mse 1e-4 bunny 295 vs 302 ms with the sort queued in every wide round)
-		sort_round = qsort_.order != nullptr && c.n_groups[last] >= qsort_.min_groups && rounds_done < 7;
+		r.sort_round = L.sort.order != nullptr && c.n_groups[r.last] >= L.sort.min_groups && r.rounds_done < 7;
 		// the stragglers: when the last round listed few expansions, few searches are still running and the chip is
 		// mostly idle -- let each of them expand more nodes per round (fewer latency-bound rounds; the extra speculation
 		// costs nothing the chip was using)
-		chunk = 4;
+		r.chunk = 4;
 		// exact: the searches that listed expansions in the last round (a search only ever finishes, so it bounds the rounds to come)
-		const int active = std::max(1, c.n_active[last]);
-		qp.kmax = std::min(kQueueMaxPop, q_list_cap_ / active);
+		const int active = std::max(1, c.n_active[r.last]);
+		qp.kmax = std::min(kQueueMaxPop, L.list_cap / active);
 		if (p_.adaptive_k && K >= 32) {
 			// <= 16 running: up to 512 expansions each (swept 1 / 2 / 4 / 8 / 16 searches: the same within the run-to-run spread)
 			qp.K = active <= 16 ? kQueueMaxPop : (active <= 64 ? std::min(kQueueRoundPop, 2 * K) : K);
 		}
 	};
-	auto wait_slot = [&](int slot) {
-		const double t1 = now_ms();
-		HIPCHK(hipEventSynchronize(ev_ctl_[slot]));
-		t_wait_ += now_ms() - t1;
-	};
-	if (!queue_ahead_) {
-		// lock-step with the host: queue a chunk, wait for it, look at it (the GPU idles ~45 us per chunk while the host decides)
-		while (true) {
-			submit(0);
-			wait_slot(0);
-			const QCtl& c = h_qctl_[0];
-			if (c.overflow) { HIPCHK(hipStreamSynchronize(stream_)); queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-			if ((c.n_groups[last_of[0]] == 0 && c.n_tile_groups[last_of[0]] == 0) || cancel_.load()) break;
-			adapt(c, last_of[0]);
-		}
-	} else {
-		// one chunk ahead (A/B only): chunk k+1 is queued before chunk k's read-back is looked at, so the GPU never waits for the host; the parameters
-		// a read-back adapts (round width, tile / sort launches, list bound) reach the chunk after next -- all of them are conservative when late
-		// (searches only finish: an older `active` count bounds the lists from above).  A batch that has ended drains the chunk in flight as no-ops.
-		// Measured (tools/queue_ahead_probe.py): bunny 33.1 -> 32.7 ms, but skull 6.39 -> 6.50, S1 11.3 -> 11.8, bunny mse 3e-5 6.75 -> 7.59 s:
-		// the late round width costs more rounds than the ~45 us bubbles per chunk it removes
-		submit(0);
-		int cur = 0;
-		while (true) {
-			submit(cur ^ 1);
-			wait_slot(cur);
-			const QCtl& c = h_qctl_[cur];
-			if (c.overflow) { HIPCHK(hipStreamSynchronize(stream_)); queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-			if ((c.n_groups[last_of[cur]] == 0 && c.n_tile_groups[last_of[cur]] == 0) || cancel_.load()) break;
-			adapt(c, last_of[cur]);
-			cur ^= 1;
+	// lock-step with the host, lane by lane: queue a chunk, wait for it, look at it (a lone lane leaves the GPU idle ~45 us per chunk while
+	// the host decides; with two lanes the other lane's chunk is running meanwhile).  Staying a chunk AHEAD of the read-backs instead was
+	// built and measured in round 4 (EXPERIMENTS R4.9): the late round width cost more rounds than the bubbles it removed -- removed again.
+	bool overflow = false;
+	for (int li = 0; li < nl; li++) submit(run[li]);
+	for (int live = nl; live > 0;) {
+		for (int li = 0; li < nl; li++) {
+			Run& r = run[li];
+			if (r.done) continue;
+			const double t1 = now_ms();
+			HIPCHK(hipEventSynchronize(r.L->ev_ctl[0]));
+			t_wait_ += now_ms() - t1;
+			const QCtl& c = r.L->h_ctl[0];
+			if (c.overflow) overflow = true;
+			if (c.overflow || overflow || (c.n_groups[r.last] == 0 && c.n_tile_groups[r.last] == 0) || cancel_.load()) { r.done = true; live--; continue; }
+			adapt(r, c);
+			submit(r);
 		}
 	}
-	// the running totals of the whole batch and the searches' results in one round trip (the chunk in flight, if any, was queued before these copies)
+	if (overflow) {
+		for (int li = 0; li < nl; li++) HIPCHK(hipStreamSynchronize(run[li].L->stream));
+		queue_fallbacks_++; cnt_.queue_fallbacks++;
+		return false;
+	}
+	// the running totals of the whole batch and the searches' results in one round trip per lane
 	const double t2 = now_ms();
-	HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
-	HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * S, hipMemcpyDeviceToHost, stream_));
-	HIPCHK(hipStreamSynchronize(stream_));
-	if (h_qctl_->overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-	cnt_.tile_expansions += h_qctl_->tile_total;
-	if (p_.verbose) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) sel_hist_[a][b] += h_qctl_->sel_hist[a][b];
-	if (p_.verbose > 1 && now_ms() - t2 > 1.0) std::fprintf(stderr, "[goicp] slow read-back of %zu search records: %.2f ms\n", S, now_ms() - t2);
-	const double t3 = now_ms();
-	for (size_t i = 0; i < S; i++) {
-		const QSearch& q = h_qsearch_[i];
-		InnerSearch& s = *searches[i];
-		s.best = q.best; s.improved = q.improved != 0; s.done = true;
-		s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
-		s.pops = q.pops; s.cubes = q.cubes; s.min_ub = q.min_ub;
+	for (int li = 0; li < nl; li++) {
+		QLane& L = *run[li].L;
+		HIPCHK(hipMemcpyAsync(L.h_ctl, L.d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, L.stream));
+		HIPCHK(hipMemcpyAsync(L.h_search, L.d_search, sizeof(QSearch) * run[li].idx.size(), hipMemcpyDeviceToHost, L.stream));
 	}
-	if (p_.verbose > 1 && now_ms() - t3 > 1.0) std::fprintf(stderr, "[goicp] slow digest of %zu search records: %.2f ms\n", S, now_ms() - t3);
+	for (int li = 0; li < nl; li++) HIPCHK(hipStreamSynchronize(run[li].L->stream));
+	for (int li = 0; li < nl; li++) if (run[li].L->h_ctl->overflow) overflow = true;
+	if (overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
+	if (nl == 2) cnt_.lane_batches++;
+	{
+		long long cubes = 0;
+		for (int li = 0; li < nl; li++) for (size_t i = 0; i < run[li].idx.size(); i++) cubes += run[li].L->h_search[i].cubes;
+		const int rounds = std::max(1, std::max(run[0].rounds_done, nl == 2 ? run[1].rounds_done : 0));
+		last_round_work_ = (double)cubes / kGroup / rounds * (double)N_;
+	}
+	for (int li = 0; li < nl; li++) {
+		const QLane& L = *run[li].L;
+		cnt_.tile_expansions += L.h_ctl->tile_total;
+		if (p_.verbose) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) sel_hist_[a][b] += L.h_ctl->sel_hist[a][b];
+		for (size_t i = 0; i < run[li].idx.size(); i++) {
+			const QSearch& q = L.h_search[i];
+			InnerSearch& s = *searches[(size_t)run[li].idx[i]];
+			s.best = q.best; s.improved = q.improved != 0; s.done = true;
+			s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
+			s.pops = q.pops; s.cubes = q.cubes; s.min_ub = q.min_ub;
+		}
+	}
 	t_collect_ += now_ms() - t2;
 	return true;
 }
@@ -1570,6 +1617,7 @@ void Engine::register_begin()
 	early_exit_ = converged_ = false;
 	rot_ramp_ = 8;
 	late_icp_.clear(); batches_done_ = 0;
+	last_round_work_ = 0;      // every registration starts single-lane (determinism: the choice depends on this registration only)
 	{ const char* e = std::getenv("GOICP_ICP_DELAY_BATCHES"); icp_delay_ = e ? std::max(0, std::atoi(e)) : 0; }
 	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
 	std::memset(level_hist_, 0, sizeof(level_hist_));
@@ -1759,10 +1807,10 @@ void Engine::flow_reset()
 	for (int i = kFlowSearches - 1; i >= 0; i--) free_search_.push_back(i);
 	for (int i = kFlowSearches / 2 - 1; i >= 0; i--) free_rot_.push_back(i);
 	q_hi_ = 0; q_parity_ = 0; flow_active_ = 0;
-	if (d_qctl_) HIPCHK(hipMemsetAsync(d_qctl_, 0, sizeof(QCtl), stream_));
+	if (ql_[0].d_ctl) HIPCHK(hipMemsetAsync(ql_[0].d_ctl, 0, sizeof(QCtl), stream_));
 	// a slot abandoned in flight (early exit, cancel) must not come back as a live search: an all-zero record is an empty
 	// queue that marks itself done at first touch
-	if (d_qsearch_) HIPCHK(hipMemsetAsync(d_qsearch_, 0, sizeof(QSearch) * cap_qsearch_, stream_));
+	if (ql_[0].d_search) HIPCHK(hipMemsetAsync(ql_[0].d_search, 0, sizeof(QSearch) * ql_[0].cap, stream_));
 }
 
 bool Engine::tiles_usable() const
@@ -1781,7 +1829,7 @@ QParams Engine::queue_params() const
 	qp.stale_compact = p_.adaptive_k && p_.stale_widen ? p_.stale_compact : 0;
 
 	qp.thr = sse_thresh_; qp.K = std::min(std::max(1, p_.trans_batch), kQueueRoundPop);
-	qp.kmax = kQueueRoundPop; qp.list_cap = q_list_cap_; qp.seg_cap = q_seg_cap_;     // any number of searches fits; run_inner_device raises kmax for the last few
+	qp.kmax = kQueueRoundPop; qp.list_cap = ql_[0].list_cap; qp.seg_cap = ql_[0].seg_cap;     // any number of searches fits; run_inner_device raises kmax for the last few
 	qp.root_x = trans_root_.x; qp.root_y = trans_root_.y; qp.root_z = trans_root_.z; qp.root_w = trans_root_.w;
 	qp.boxed = trans_boxed_ ? 1 : 0; qp.depth = p_.trans_search_depth;
 	qp.cap = (p_.queue_cap > 0 && p_.queue_cap < kQueueCap) ? p_.queue_cap : kQueueCap;
@@ -1861,7 +1909,7 @@ int Engine::flow_step(int max_rot_pops)
 				if (n) {
 					HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * (kFlowSearches / 2), hipMemcpyHostToDevice, stream_));
 					HIPCHK(hipMemcpyAsync(d_qinit_, h_qinit_, sizeof(QInit) * n, hipMemcpyHostToDevice, stream_));
-					HIPCHK(launch_bnb_init_list(d_qsearch_, d_qnodes_, d_qinit_, n, qp, stream_));
+					HIPCHK(launch_bnb_init_list(ql_[0].d_search, ql_[0].d_nodes, d_qinit_, n, qp, stream_));
 					flow_active_ += n;
 				}
 			}
@@ -1873,30 +1921,30 @@ int Engine::flow_step(int max_rot_pops)
 		if (p_.adaptive_k && qp.K >= 32) qr.K = flow_active_ <= 16 ? kQueueRoundPop : (flow_active_ <= 64 ? std::min(kQueueRoundPop, 2 * qp.K) : qp.K);
 		// most the round can list: the queue kernel widens a stale search's step up to x4 (stale_widen), as in run_inner_device --
 		// sizing the evaluation's grid by q_hi_ * K left the expansions listed beyond it unevaluated in trimmed runs (one workgroup each)
-		const int max_groups = (int)std::min<size_t>((size_t)q_hi_ * (size_t)std::min(qr.kmax, 4 * qr.K), (size_t)q_list_cap_);
+		const int max_groups = (int)std::min<size_t>((size_t)q_hi_ * (size_t)std::min(qr.kmax, 4 * qr.K), (size_t)ql_[0].list_cap);
 		for (int r = 0; r < 3; r++) {
-			HIPCHK(launch_bnb_queue(d_qsearch_, d_qnodes_, q_hi_, qr, d_qparents_[q_parity_ ^ 1], d_qparents_[q_parity_], d_qub_, d_qlb_, d_qscratch_, d_qctl_, q_parity_, stream_));
-			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, d_qparents_[q_parity_], &d_qctl_->n_groups[q_parity_], &d_qctl_->work[q_parity_][0], &d_qctl_->chunks,
-			                           max_groups, inliers_, d_qscratch_, d_qub_, d_qlb_, stream_));
+			HIPCHK(launch_bnb_queue(ql_[0].d_search, ql_[0].d_nodes, q_hi_, qr, ql_[0].d_parents[q_parity_ ^ 1], ql_[0].d_parents[q_parity_], ql_[0].d_ub, ql_[0].d_lb, ql_[0].d_scratch, ql_[0].d_ctl, q_parity_, stream_));
+			HIPCHK(launch_bounds_queue(d_src_, (int)N_, bounds_dt(), d_rots_, ql_[0].d_parents[q_parity_], &ql_[0].d_ctl->n_groups[q_parity_], &ql_[0].d_ctl->work[q_parity_][0], &ql_[0].d_ctl->chunks,
+			                           max_groups, inliers_, ql_[0].d_scratch, ql_[0].d_ub, ql_[0].d_lb, stream_));
 			q_parity_ ^= 1;
 			cnt_.bounds_launches++;
 			queue_rounds_++;
 		}
-		HIPCHK(hipMemcpyAsync(h_qctl_, d_qctl_, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
-		HIPCHK(hipMemcpyAsync(h_qsearch_, d_qsearch_, sizeof(QSearch) * (size_t)q_hi_, hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(ql_[0].h_ctl, ql_[0].d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, stream_));
+		HIPCHK(hipMemcpyAsync(ql_[0].h_search, ql_[0].d_search, sizeof(QSearch) * (size_t)q_hi_, hipMemcpyDeviceToHost, stream_));
 		t_submit_ += now_ms() - t0;
 		const double t1 = now_ms();
 		HIPCHK(hipStreamSynchronize(stream_));
 		t_wait_ += now_ms() - t1;
-		if (h_qctl_->overflow) { flow_fallback(); continue; }
+		if (ql_[0].h_ctl->overflow) { flow_fallback(); continue; }
 		// ---- harvest: every child whose two searches have stopped, in admission order ----
 		const double t2 = now_ms();
 		int active = 0;
 		bool stop = false;
 		for (Flight& f : flights_) {
 			if (f.handled) continue;
-			const QSearch& u = h_qsearch_[f.s_ub];
-			const QSearch& l = h_qsearch_[f.s_lb];
+			const QSearch& u = ql_[0].h_search[f.s_ub];
+			const QSearch& l = ql_[0].h_search[f.s_lb];
 			// a search that has stopped has no pending children: done is only set in the selection phase, after the digest
 			if (!u.done || !l.done) { active += (u.done ? 0 : 1) + (l.done ? 0 : 1); continue; }
 			f.handled = true;

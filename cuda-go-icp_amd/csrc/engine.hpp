@@ -55,6 +55,9 @@ struct Params {
 	int stale_compact = 2048;     // a proving inner search whose queue holds at least this many nodes selects by Morton order of the cubes' corners instead of by lower
 	                              // bound (spatially compact, depth-first-like: LDS-tile material, and the slab stops overflowing); 0: always by lower bound
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
+	int lanes = 0;                // 2 (always) / 0 (auto: when the previous batch's rounds were throughput-bound; default) / 1 (never): a batch of at least lane_min_searches inner searches is cut in two by rotation slot and the halves run their lock-step rounds side by side
+	                              // on two streams (own lists, own control block): one half's dependent launches drain beside the other's (run_inner_device)
+	int lane_min_searches = 64;
 	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -72,6 +75,7 @@ struct Counters {
 	long long bounds_launches = 0;
 	long long queue_fallbacks = 0;
 	long long tile_expansions = 0;   // BnB expansions evaluated from LDS-staged DT tiles (8 cube bounds each; counted in `cubes` too)
+	long long lane_batches = 0;      // batches of inner searches that ran as two lanes
 };
 
 // what the viewer polls (fgoicp.hpp:34,67-69; goicp_kernel.cu:161-177)
@@ -266,22 +270,30 @@ private:
 		float* d_ub = nullptr; float* h_ub = nullptr;   // ub[B] followed by lb[B]
 		size_t cap = 0, B = 0; hipEvent_t ev = nullptr;
 	} stage_[2];
-	// device-resident inner-BnB queues (bnbqueue.hip)
-	size_t cap_qsearch_ = 0;
-	QSearch* d_qsearch_ = nullptr; QSearch* h_qsearch_ = nullptr;
-	QNode* d_qnodes_ = nullptr;
-	ParentRec* d_qparents_[2] = {nullptr, nullptr};
-	QSort qsort_{};                                     // footprint-ordered items of large rounds (device.hip); order == nullptr: off
-	int q_list_cap_ = 0;                                // expansions the round's lists (parents, bounds, partial sums) hold
-	int q_seg_cap_ = 0;                                 // segments the tile list holds (q_list_cap_ / 64 + search slots)
-	int* d_qpsearch_[2] = {nullptr, nullptr};          // per listed expansion: the search that listed it (twin test of the bound evaluation)
-	float* d_qub_ = nullptr; float* d_qlb_ = nullptr; float* d_qscratch_ = nullptr;
-	QCtl* d_qctl_ = nullptr; QCtl* h_qctl_ = nullptr;       // h_qctl_: two pinned snapshots (one per chunk of rounds in flight)
-	hipEvent_t ev_ctl_[2] = {nullptr, nullptr};
-	int queue_ahead_ = 0;                                   // env GOICP_QUEUE_AHEAD = 1 (A/B only): the host stays one chunk of rounds ahead of the read-backs.  Measured: no gain (EXPERIMENTS R4.9)
-	QTile qtile_{};                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
+	// device-resident inner-BnB queues (bnbqueue.hip).  A LANE is one self-contained set of them -- search slots, node slabs, the
+	// round's two expansion lists with their bounds and partial sums, the sort buffers, the control block with its pinned snapshots --
+	// driven on its own stream.  Lane 0 always exists; lane 1 is created for batches cut in two (Params::lanes, run_inner_device)
+	struct QLane {
+		hipStream_t stream = nullptr;
+		size_t cap = 0;                                     // search slots
+		QSearch* d_search = nullptr; QSearch* h_search = nullptr;
+		QNode* d_nodes = nullptr;
+		ParentRec* d_parents[2] = {nullptr, nullptr};
+		QSort sort{};                                       // footprint-ordered items of large rounds (device.hip); order == nullptr: off
+		int list_cap = 0;                                   // expansions the round's lists (parents, bounds, partial sums) hold
+		int seg_cap = 0;                                    // segments the tile list holds (list_cap / 64 + search slots)
+		int* d_psearch[2] = {nullptr, nullptr};             // per listed expansion: the search that listed it (twin test of the bound evaluation)
+		float* d_ub = nullptr; float* d_lb = nullptr; float* d_scratch = nullptr;
+		QCtl* d_ctl = nullptr; QCtl* h_ctl = nullptr;       // h_ctl: two pinned snapshots (one per chunk of rounds in flight)
+		hipEvent_t ev_ctl[2] = {nullptr, nullptr};
+		QTile tile{};                                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
+		int tile_hint_seen = 0;                             // QCtl::tile_hint at the last read-back
+	} ql_[2];
+	void free_lane(QLane& L);
+	void ensure_lane(int li, size_t nsearch);
+	double last_round_work_ = 0, lane_min_work_ = 64e6;    // point-expansions (expansions x source points) of the previous batch's mean round / the auto mode's bar
+	int lanes_ = 0, lane_min_searches_ = 64;                // Params::lanes / lane_min_searches (env GOICP_LANES / GOICP_LANE_MIN override, tuning only)
 	bool tiles_usable() const;
-	int tile_hint_seen_ = 0;              // QCtl::tile_hint at the last read-back
 	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration
 	long long tile_rounds_ = 0;           // rounds whose tile evaluation was launched
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;

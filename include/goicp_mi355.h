@@ -179,6 +179,13 @@ typedef struct goicp_params {
 	/* (icp_nn_cache, above: 2 = the exact neighbour cache switched on in the tail of a run only -- round 4, measured +0..3 %, opt-in) */
 	int32_t stream_priority; /* 0 (default): the engine's HIP stream has the default priority; 1: the highest the device offers (hipStreamCreateWithPriority)
 	                          * -- for a latency-bound engine (an ICP loop) that shares the GPU with a throughput engine; measured: tools/overlap_probe.py */
+	int32_t lanes;           /* two-lane rounds of the device-queue search (round 4): a batch of at least lane_min_searches inner searches (GoICP::InnerBnB
+	                          * calls, jly_goicp.cpp:227-340 -- independent of each other) is cut in two by rotation child and the halves run their
+	                          * lock-step rounds side by side on two HIP streams, each with its own lists and control block, so one half's dependent launches
+	                          * drain beside the other's.  0 (default): when the previous batch's mean round was throughput-bound (>= 64 M point-expansions:
+	                          * a count, so the choice is deterministic); 1: never; 2: every batch of at least lane_min_searches.  Same searches, same bounds,
+	                          * same results per search; measured (tools/lanes_probe.py): prove-the-optimum bunny 6.74 -> 5.7 s, default registrations unchanged */
+	int32_t lane_min_searches; /* default 64 */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);
@@ -257,6 +264,7 @@ typedef struct goicp_counters {
 	int64_t rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters, bounds_launches;
 	int64_t queue_fallbacks;     /* batches of inner searches re-run through the host queues because a device queue outgrew its slab */
 	int64_t tile_expansions;     /* BnB expansions (8 cube bounds each, counted in `cubes` too) evaluated from LDS-staged DT tiles */
+	int64_t lane_batches;        /* batches of inner searches that ran as two lanes (goicp_params::lanes) */
 } goicp_counters;
 int goicp_inner_bnb(goicp_handle h, const float R[9], int32_t level, float incumbent, float* value,
                     float best_node[4], goicp_counters* counters);

@@ -503,6 +503,61 @@ def _e2e_counts(eng, g):
     assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"], (c.trans_pops, g["tNodeCount"])
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_two_lane_rounds_prove_the_reference_optimum(pkg, lanes):
+    """goicp_params::lanes: a batch of inner searches (GoICP::InnerBnB calls, jly_goicp.cpp:227-340 -- independent of each other) cut in two by
+    rotation child, the halves run their lock-step rounds side by side on two streams (engine.cpp run_inner_device).  Per search nothing changes
+    (same bounds, same stop and prune rules), so with the cut forced on every batch (lanes = 2, lane_min_searches = 2) the converged search of
+    a small seeded problem meets the same bars against the reference's own GoICP::Register (tests/golden/e2e_small4.json) as with one lane,
+    and the counters say which path ran."""
+    from conftest import small_problem
+    tgt, src, _, _ = small_problem(4)
+    g = golden("e2e_small4")
+    eng = pkg.FastGoICP(tgt, src, g["mse_threshold"], lanes=lanes, lane_min_searches=2)
+    eng.run()
+    c = eng.counters
+    sse = float(eng.get_best_error())
+    ang, dt = rot_angle(eng.optR, np.array(g["R"])), float(np.linalg.norm(eng.optT - np.array(g["t"])))
+    print("lanes %d: sse %.7g (reference %.7g) rot_error %.2e trans_error %.2e rotation nodes %d (reference %d) cube bounds %d two-lane batches %d" % (
+        lanes, sse, g["sse"], ang, dt, c.rot_pops, g["rNodeCount"], c.cubes, c.lane_batches))
+    assert eng.finished and abs(sse - g["sse"]) <= 1e-5 * g["sse"]
+    assert ang <= 1e-5 and dt <= 1e-5, (ang, dt)
+    assert abs(c.rot_pops - g["rNodeCount"]) <= 0.01 * g["rNodeCount"]
+    assert abs(c.cubes - 8 * g["tNodeCount"]) <= 0.05 * 8 * g["tNodeCount"]
+    assert c.queue_fallbacks == 0
+    assert (c.lane_batches > 0) == (lanes == 2)
+    eng.registration.close()
+
+
+def test_auto_lanes_are_deterministic_and_change_no_result(pkg, bunny_model, bunny_data):
+    """lanes = 0 (the default) cuts a batch in two when the PREVIOUS batch's mean round was throughput-bound -- a count of point-expansions, not
+    a time -- so two runs of one engine take the same path: identical counters, identical result.  Bunny at mse 1e-4 (the search proves the
+    optimum: 994 rotation nodes, 8.8 M cube bounds) has such batches; its result equals the single-lane run's (same SSE to 1e-6 relative,
+    same pose, same rotation nodes; cube bounds within 0.1 %: the adaptive round width follows each lane's own count of running searches).
+    The default registration (mse 1e-3: early exit after 384 rotation nodes) never qualifies."""
+    auto = pkg.FastGoICP(bunny_model, bunny_data, 1e-4)
+    one = pkg.FastGoICP(bunny_model, bunny_data, 1e-4, lanes=1)
+    seen = []
+    for _ in range(2):
+        auto.run()
+        c = auto.counters
+        seen.append((float(auto.get_best_error()), auto.optR.tobytes(), auto.optT.tobytes(), c.cubes, c.rot_pops, c.trans_pops, c.icp_iters, c.lane_batches, c.bounds_launches))
+    assert seen[0] == seen[1], (seen[0][3:], seen[1][3:])
+    one.run()
+    ca, c1 = auto.counters, one.counters
+    print("auto lanes: %d two-lane batches, cube bounds %d vs %d (one lane), rotation nodes %d vs %d, sse %.7g vs %.7g" % (
+        ca.lane_batches, ca.cubes, c1.cubes, ca.rot_pops, c1.rot_pops, auto.get_best_error(), one.get_best_error()))
+    assert ca.lane_batches > 0 and c1.lane_batches == 0
+    assert abs(auto.get_best_error() - one.get_best_error()) <= 1e-6 * one.get_best_error()
+    assert rot_angle(auto.optR, one.optR) <= 1e-6 and float(np.linalg.norm(auto.optT - one.optT)) <= 1e-6
+    assert ca.rot_pops == c1.rot_pops and abs(ca.cubes - c1.cubes) <= 1e-3 * c1.cubes
+    shallow = pkg.FastGoICP(bunny_model, bunny_data, 1e-3)
+    shallow.run()
+    assert shallow.counters.lane_batches == 0
+    for e in (auto, one, shallow):
+        e.registration.close()
+
+
 @pytest.mark.parametrize("seed", [1, 4, 6, 8])
 def test_e2e_small_proven_optimum(pkg, seed):
     """The converged-search counterpart of the early-exit fixtures: small seeded problems (conftest.small_problem: 400-point target, 150-point

@@ -34,9 +34,9 @@ def test_struct_sizes_match_abi(pkg):
     from cuda_go_icp_amd import binding as B
     import ctypes as C
     assert C.sizeof(B.CCube) == 24
-    assert C.sizeof(B.CCounters) == 72
+    assert C.sizeof(B.CCounters) == 80
     assert C.sizeof(B.CStepStatus) == 24
-    assert C.sizeof(B.CResult) == 4 * (9 + 3 + 9 + 3 + 1 + 1) + 72 + 16
+    assert C.sizeof(B.CResult) == 4 * (9 + 3 + 9 + 3 + 1 + 1) + 80 + 16
 
 
 CFG = """# comment

@@ -155,6 +155,8 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	HIPCHK(hipEventCreate(&ev0_));
 	HIPCHK(hipEventCreate(&ev1_));
 	HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+	lane_stream_[0] = stream_; lane_stream_[1] = stream2_;
+	for (int k = 2; k < kMaxLanes; k++) HIPCHK(hipStreamCreateWithFlags(&lane_stream_[k], hipStreamNonBlocking));
 	HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
 	{ const char* e = std::getenv("GOICP_TILE_CONCURRENT"); if (e) tile_concurrent_ = std::atoi(e) != 0; }     // A/B only (tools/tile_deep.py)
@@ -162,6 +164,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	{ const char* e = std::getenv("GOICP_LANES"); if (e) lanes_ = std::atoi(e); }                                  // tuning only (tools/lanes_probe.py)
 	{ const char* e = std::getenv("GOICP_LANE_MIN"); if (e) lane_min_searches_ = std::max(2, std::atoi(e)); }
 	{ const char* e = std::getenv("GOICP_LANE_MIN_WORK"); if (e) lane_min_work_ = std::atof(e); }
+	{ const char* e = std::getenv("GOICP_AUTO_LANES"); if (e) auto_lanes_ = std::min(kMaxLanes, std::max(2, std::atoi(e))); }
 
 	h_target_.assign(target, target + 3 * M);
 	if (!(p_.trim_fraction >= 0.f) || p_.trim_fraction >= 1.f) throw std::invalid_argument("goicp: trim_fraction must be in [0,1)");
@@ -566,6 +569,8 @@ void Engine::release()
 	if (ev0_) hipEventDestroy(ev0_);
 	if (ev1_) hipEventDestroy(ev1_);
 	if (stream2_) { hipStreamSynchronize(stream2_); hipStreamDestroy(stream2_); }
+	for (int k = 2; k < kMaxLanes; k++) if (lane_stream_[k]) { hipStreamSynchronize(lane_stream_[k]); hipStreamDestroy(lane_stream_[k]); }
+	for (int k = 0; k < kMaxLanes; k++) lane_stream_[k] = nullptr;
 	if (ev_fork_) hipEventDestroy(ev_fork_);
 	if (ev_join_) hipEventDestroy(ev_join_);
 	stream2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
@@ -1148,7 +1153,7 @@ void Engine::ensure_queues(size_t nsearch) { ensure_lane(0, nsearch); }
 void Engine::ensure_lane(int li, size_t nsearch)
 {
 	QLane& L = ql_[li];
-	L.stream = li == 0 ? stream_ : stream2_;
+	L.stream = lane_stream_[li];
 	if (nsearch <= L.cap) return;
 	// first use: room for a full round of the outer search (rot_batch parents x 8 children x {ub, lb} pass) -- growing in
 	// steps would re-allocate the 196 KB-per-search slabs several times in the first rounds
@@ -1231,16 +1236,17 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	std::memcpy(h_rots_, rots.data(), sizeof(Rot9) * nrot);
 	HIPCHK(hipMemcpyAsync(d_rots_, h_rots_, sizeof(Rot9) * nrot, hipMemcpyHostToDevice, stream_));
 	// Lanes: the searches of a batch are independent of each other (own queue, own incumbent; only the two passes of one rotation child --
-	// twins, same rotation slot -- share loads), so a large batch is cut in two by rotation slot and each half runs its own lock-step rounds
+	// twins, same rotation slot -- share loads), so a large batch is cut into lanes by rotation slot and each lane runs its own lock-step rounds
 	// on its own stream with its own lists and control block.  Same bounds, same stop and prune rules per search; what changes is that one
-	// lane's dependent launches (queue kernel -> sort -> bound evaluation, each draining before the next starts) run beside the other's.
-	// ... which pays when a round is throughput-bound (its kernels' drain tails are what the other lane fills) and costs when it is latency-bound
-	// (two half rounds take longer than one whole).  Measured (tools/lanes_probe.py, one lane -> two): rounds of 416 M point-expansions (bunny,
-	// mse 3e-5) 6.74 -> 5.67 s, 183 M (synthetic 40 k, mse 3e-5) 724 -> 659 ms, 90 M (bunny, mse 1e-4) 269 -> 264 ms, 39 M (3 k points, mse 3e-5)
-	// 1.10 -> 1.22 s, 20 M (the default bunny registration) 33.7 -> 34.2 ms.  So lanes = 0 (auto) cuts a batch in two when the PREVIOUS batch's
-	// mean round was at least lane_min_work_ point-expansions -- a count, not a time: the choice is deterministic
+	// lane's dependent launches (queue kernel -> sort -> bound evaluation, each draining before the next starts) run beside the others'.
+	// That pays when a round is throughput-bound (its kernels' drain tails are what the other lanes fill) and costs when it is latency-bound
+	// (the parts of a round take longer than the whole).  Measured (tools/lanes_probe.py; one lane -> two always -> auto with three):
+	// rounds of 416 M point-expansions (bunny, mse 3e-5) 6.74 -> 5.71 -> 5.71 s, 183 M (synthetic 40 k, mse 3e-5) 721 -> 669 -> 649 ms, 90 M (bunny,
+	// mse 1e-4) 269 -> 264 -> 262 ms, 39 M (3 k points, mse 3e-5) 1.10 -> 1.22 -> 1.02 s (its heavy batches only), 20 M (the default bunny
+	// registration) 33.7 -> 34.2 -> 33.1 ms (never cut).  So lanes = 0 (auto) cuts a batch when the PREVIOUS batch's mean round was at least
+	// lane_min_work_ point-expansions (swept 16 / 32 / 64 / 128 / 256 M: 64 M) -- a count, not a time: the choice is deterministic
 	const bool lanes_wanted = lanes_ >= 2 || (lanes_ == 0 && last_round_work_ >= lane_min_work_);
-	const int nl = (lanes_wanted && S >= (size_t)lane_min_searches_ && stream2_) ? 2 : 1;
+	int nl = (lanes_wanted && S >= (size_t)lane_min_searches_ && stream2_) ? std::min(kMaxLanes, lanes_ >= 2 ? lanes_ : auto_lanes_) : 1;
 	struct Run {
 		QLane* L = nullptr;
 		std::vector<int> idx;                 // lane slot -> index into `searches`
@@ -1248,13 +1254,16 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		int parity = 0, chunk = 3, rounds_done = 0, last = 0;
 		long long round_cap = 0;
 		bool sort_round = false, tiles = false, twins = false, done = false;
-	} run[2];
+	} run[kMaxLanes];
+	if (nl > 1) {
+		for (size_t i = 0; i < S; i++) run[searches[i]->rot_slot % nl].idx.push_back((int)i);
+		for (int li = 0; li < nl; li++) if (run[li].idx.empty()) nl = 1;           // (a batch whose slots all fall into one class: not worth a lane)
+		if (nl == 1) for (Run& r : run) r.idx.clear();
+	}
 	if (nl == 1) { run[0].idx.resize(S); for (size_t i = 0; i < S; i++) run[0].idx[i] = (int)i; }
-	else for (size_t i = 0; i < S; i++) run[searches[i]->rot_slot & 1].idx.push_back((int)i);
-	if (nl == 2 && (run[0].idx.empty() || run[1].idx.empty())) throw std::logic_error("goicp: a lane without searches");
-	if (nl == 2) {            // lane 1 starts behind the rotation upload (and everything else queued on the engine's stream)
+	if (nl > 1) {            // the other lanes start behind the rotation upload (and everything else queued on the engine's stream)
 		HIPCHK(hipEventRecord(ev_fork_, stream_));
-		HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+		for (int li = 1; li < nl; li++) HIPCHK(hipStreamWaitEvent(lane_stream_[li], ev_fork_, 0));
 	}
 	for (int li = 0; li < nl; li++) {
 		Run& r = run[li];
@@ -1390,11 +1399,12 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	for (int li = 0; li < nl; li++) HIPCHK(hipStreamSynchronize(run[li].L->stream));
 	for (int li = 0; li < nl; li++) if (run[li].L->h_ctl->overflow) overflow = true;
 	if (overflow) { queue_fallbacks_++; cnt_.queue_fallbacks++; return false; }
-	if (nl == 2) cnt_.lane_batches++;
+	if (nl > 1) cnt_.lane_batches++;
 	{
 		long long cubes = 0;
 		for (int li = 0; li < nl; li++) for (size_t i = 0; i < run[li].idx.size(); i++) cubes += run[li].L->h_search[i].cubes;
-		const int rounds = std::max(1, std::max(run[0].rounds_done, nl == 2 ? run[1].rounds_done : 0));
+		int rounds = 1;
+		for (int li = 0; li < nl; li++) rounds = std::max(rounds, run[li].rounds_done);
 		last_round_work_ = (double)cubes / kGroup / rounds * (double)N_;
 	}
 	for (int li = 0; li < nl; li++) {

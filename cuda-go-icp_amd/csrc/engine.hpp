@@ -55,8 +55,9 @@ struct Params {
 	int stale_compact = 2048;     // a proving inner search whose queue holds at least this many nodes selects by Morton order of the cubes' corners instead of by lower
 	                              // bound (spatially compact, depth-first-like: LDS-tile material, and the slab stops overflowing); 0: always by lower bound
 	int tile_min = 8;             // ... and at least this many expansions (a lane group of the tile kernel is one expansion)
-	int lanes = 0;                // 2 (always) / 0 (auto: when the previous batch's rounds were throughput-bound; default) / 1 (never): a batch of at least lane_min_searches inner searches is cut in two by rotation slot and the halves run their lock-step rounds side by side
-	                              // on two streams (own lists, own control block): one half's dependent launches drain beside the other's (run_inner_device)
+	int lanes = 0;                // n = 2..4 (always n) / 0 (auto: three, when the previous batch's rounds were throughput-bound; default) / 1 (never): a batch of at least
+	                              // lane_min_searches inner searches is cut into lanes by rotation slot and the lanes run their lock-step rounds side by side on their own
+	                              // streams (own lists, own control block): one lane's dependent launches drain beside the others' (run_inner_device)
 	int lane_min_searches = 64;
 	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
@@ -273,6 +274,7 @@ private:
 	// device-resident inner-BnB queues (bnbqueue.hip).  A LANE is one self-contained set of them -- search slots, node slabs, the
 	// round's two expansion lists with their bounds and partial sums, the sort buffers, the control block with its pinned snapshots --
 	// driven on its own stream.  Lane 0 always exists; lane 1 is created for batches cut in two (Params::lanes, run_inner_device)
+	static constexpr int kMaxLanes = 4;
 	struct QLane {
 		hipStream_t stream = nullptr;
 		size_t cap = 0;                                     // search slots
@@ -288,10 +290,13 @@ private:
 		hipEvent_t ev_ctl[2] = {nullptr, nullptr};
 		QTile tile{};                                       // the tile list's buffers (null when lds_tiles == 0 or the DT is not bricked fp32)
 		int tile_hint_seen = 0;                             // QCtl::tile_hint at the last read-back
-	} ql_[2];
+	} ql_[kMaxLanes];
+	hipStream_t lane_stream_[kMaxLanes] = {};               // lane 0: stream_, lane 1: stream2_, further lanes: their own
 	void free_lane(QLane& L);
 	void ensure_lane(int li, size_t nsearch);
 	double last_round_work_ = 0, lane_min_work_ = 64e6;    // point-expansions (expansions x source points) of the previous batch's mean round / the auto mode's bar
+	int auto_lanes_ = 3;                                    // lanes the auto mode cuts a batch into (env GOICP_AUTO_LANES; measured 2 / 3 / 4: bunny mse 3e-5 5.71 / 5.71 / 5.67 s,
+	                                                        // synthetic 40 k mse 3e-5 667 / 649 / 654 ms, 3 k points mse 3e-5 1 039 / 1 020 / 1 002 ms, bunny mse 1e-4 262 / 262 / 262 ms)
 	int lanes_ = 0, lane_min_searches_ = 64;                // Params::lanes / lane_min_searches (env GOICP_LANES / GOICP_LANE_MIN override, tuning only)
 	bool tiles_usable() const;
 	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration

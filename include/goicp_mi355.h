@@ -179,12 +179,13 @@ typedef struct goicp_params {
 	/* (icp_nn_cache, above: 2 = the exact neighbour cache switched on in the tail of a run only -- round 4, measured +0..3 %, opt-in) */
 	int32_t stream_priority; /* 0 (default): the engine's HIP stream has the default priority; 1: the highest the device offers (hipStreamCreateWithPriority)
 	                          * -- for a latency-bound engine (an ICP loop) that shares the GPU with a throughput engine; measured: tools/overlap_probe.py */
-	int32_t lanes;           /* two-lane rounds of the device-queue search (round 4): a batch of at least lane_min_searches inner searches (GoICP::InnerBnB
-	                          * calls, jly_goicp.cpp:227-340 -- independent of each other) is cut in two by rotation child and the halves run their
-	                          * lock-step rounds side by side on two HIP streams, each with its own lists and control block, so one half's dependent launches
-	                          * drain beside the other's.  0 (default): when the previous batch's mean round was throughput-bound (>= 64 M point-expansions:
-	                          * a count, so the choice is deterministic); 1: never; 2: every batch of at least lane_min_searches.  Same searches, same bounds,
-	                          * same results per search; measured (tools/lanes_probe.py): prove-the-optimum bunny 6.74 -> 5.7 s, default registrations unchanged */
+	int32_t lanes;           /* lanes of the device-queue search (round 4): a batch of at least lane_min_searches inner searches (GoICP::InnerBnB calls,
+	                          * jly_goicp.cpp:227-340 -- independent of each other) is cut into lanes by rotation child and the lanes run their lock-step
+	                          * rounds side by side on their own HIP streams, each with its own lists and control block, so one lane's dependent launches
+	                          * drain beside the others'.  0 (default): three lanes when the previous batch's mean round was throughput-bound (>= 64 M
+	                          * point-expansions: a count, so the choice is deterministic); 1: never; 2..4: that many, for every batch of at least
+	                          * lane_min_searches.  Same searches, same bounds, same result per search; measured (tools/lanes_probe.py): prove-the-optimum
+	                          * bunny 6.74 -> 5.7 s, synthetic 40 k 721 -> 649 ms, default (early-exit) registrations never qualify and are unchanged */
 	int32_t lane_min_searches; /* default 64 */
 } goicp_params;
 

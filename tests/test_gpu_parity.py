@@ -503,13 +503,13 @@ def _e2e_counts(eng, g):
     assert abs(c.trans_pops - g["tNodeCount"]) <= 0.02 * g["tNodeCount"], (c.trans_pops, g["tNodeCount"])
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_two_lane_rounds_prove_the_reference_optimum(pkg, lanes):
-    """goicp_params::lanes: a batch of inner searches (GoICP::InnerBnB calls, jly_goicp.cpp:227-340 -- independent of each other) cut in two by
-    rotation child, the halves run their lock-step rounds side by side on two streams (engine.cpp run_inner_device).  Per search nothing changes
-    (same bounds, same stop and prune rules), so with the cut forced on every batch (lanes = 2, lane_min_searches = 2) the converged search of
-    a small seeded problem meets the same bars against the reference's own GoICP::Register (tests/golden/e2e_small4.json) as with one lane,
-    and the counters say which path ran."""
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_lanes_prove_the_reference_optimum(pkg, lanes):
+    """goicp_params::lanes: a batch of inner searches (GoICP::InnerBnB calls, jly_goicp.cpp:227-340 -- independent of each other) cut into lanes
+    by rotation child, the lanes run their lock-step rounds side by side on their own streams (engine.cpp run_inner_device).  Per search nothing
+    changes (same bounds, same stop and prune rules), so with the cut forced on every batch (lanes = 2 / 4, lane_min_searches = 2) the converged
+    search of a small seeded problem meets the same bars against the reference's own GoICP::Register (tests/golden/e2e_small4.json) as with
+    one lane, and the counters say which path ran."""
     from conftest import small_problem
     tgt, src, _, _ = small_problem(4)
     g = golden("e2e_small4")
@@ -525,7 +525,7 @@ def test_two_lane_rounds_prove_the_reference_optimum(pkg, lanes):
     assert abs(c.rot_pops - g["rNodeCount"]) <= 0.01 * g["rNodeCount"]
     assert abs(c.cubes - 8 * g["tNodeCount"]) <= 0.05 * 8 * g["tNodeCount"]
     assert c.queue_fallbacks == 0
-    assert (c.lane_batches > 0) == (lanes == 2)
+    assert (c.lane_batches > 0) == (lanes >= 2)
     eng.registration.close()
 
 

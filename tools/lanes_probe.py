@@ -15,14 +15,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     else:
         from cuda_go_icp_amd import synth
         model, data, _, _ = synth.make_pair(**{k: synth.S1[k] for k in ("seed", "M", "N")})
-    eng = pkg.FastGoICP(model, data, mse)
+    kw = {k: int(v) for k, v in (a.split('=') for a in os.environ.get('GOICP_PROBE_KW', '').split(',') if a)}      # e.g. rot_batch=128
+    eng = pkg.FastGoICP(model, data, mse, **kw)
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter(); eng.run(); ts.append(time.perf_counter() - t0)
     c = eng.counters
     t = float(np.median(ts[1:])) if len(ts) > 2 else min(ts)
-    print("%-8s mse %g lanes %s min %s work %s: %9.2f ms  cube bounds %d  rot nodes %d  rounds %d  icp %d  sse %.7g  R00 %.7f" % (
-        which, mse, os.environ.get("GOICP_LANES", "default"), os.environ.get("GOICP_LANE_MIN", "default"), os.environ.get("GOICP_LANE_MIN_WORK", "default"), 1e3 * t, c.cubes, c.rot_pops, c.bounds_launches, c.icp_iters,
+    print("%-8s %s mse %g lanes %s min %s work %s auto-lanes %s: %9.2f ms  cube bounds %d  rot nodes %d  rounds %d  icp %d  sse %.7g  R00 %.7f" % (
+        which, os.environ.get('GOICP_PROBE_KW', ''), mse, os.environ.get("GOICP_LANES", "default"), os.environ.get("GOICP_LANE_MIN", "default"), os.environ.get("GOICP_LANE_MIN_WORK", "default"), os.environ.get("GOICP_AUTO_LANES", "default"), 1e3 * t, c.cubes, c.rot_pops, c.bounds_launches, c.icp_iters,
         eng.get_best_error(), eng.optR[0, 0]), flush=True)
 else:
     sets = [a for a in sys.argv[1:] if ":" in a] or ["1:64", "2:64", "0:64"]
@@ -34,4 +35,5 @@ else:
             lanes, mn, *work = st.split(":")
             env = dict(os.environ); env["GOICP_LANES"] = lanes; env["GOICP_LANE_MIN"] = mn
             if work: env["GOICP_LANE_MIN_WORK"] = work[0]
+            if len(work) > 1: env["GOICP_AUTO_LANES"] = work[1]
             subprocess.run([sys.executable, os.path.abspath(__file__), "child", which, mse, str(reps)], env=env)

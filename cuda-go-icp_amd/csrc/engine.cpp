@@ -2084,7 +2084,7 @@ void Engine::run()
 	double t0 = now_ms();
 	register_begin();
 	while (true) {
-		StepStatus st = register_step(flow_mode() ? (1 << 20) : 64);     // the flow drains its in-flight searches at the end of a step
+		StepStatus st = register_step(flow_mode() ? (1 << 20) : std::max(64, p_.rot_batch));     // one batch per step at full ramp (the flow drains its in-flight searches at the end of a step)
 		if (st.finished) break;
 	}
 	register_ms_ = now_ms() - t0;

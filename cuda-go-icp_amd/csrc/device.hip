@@ -252,11 +252,16 @@ __device__ __forceinline__ bool is_sibling_set(const CubeRec cr[kGroup])
 // bit-identical bounds.  NP = 2: the SAME expansion listed by both searches of a rotation child (coeff[0] = the lower-bound pass's
 // coefficient, coeff[1] = 0 of the upper-bound pass): one gather serves both, only the subtraction of the rotation radius and the
 // sums are per pass -- each pass's sums see exactly the operations of a separate evaluation.
-template <int LAYOUT, int NP>
+// LAST_ZERO: coeff[NP - 1] is known to be 0 (the upper-bound pass, jly_goicp.cpp:284-285 with maxRotDis = 0): its residual is the looked-up
+// distance itself -- v - 0 and max(v, 0) are v bit for bit, the DT holds no negative value -- so the subtraction and the clamp are not issued.
+template <int LAYOUT, int NP, bool LAST_ZERO>
 __device__ __forceinline__ void lean_points(const float4* __restrict__ src, int p0, int p1, const DtDesc& dt, const Rot9& R0, const SiblingSet& ts, float delta,
                                             const float (&coeff)[NP], f2 (&ub2)[NP][4], f2 (&lb2)[NP][4])
 {
-	const f2 delta2 = f2{delta, delta};
+	const f2 delta2 = f2{delta, delta}, ndelta2 = f2{-delta, -delta};
+	// one bound for the six margins: on the unchecked branch below every index is inside the grid, i.e. |F| < V, and eps(F) = c1 + c2 |F| grows with
+	// |F|; a lane whose F lies outside takes the checked branch, which tests for itself (16 instead of 30 instructions for the test)
+	const float eps_grid = __fmaf_rn((float)(dt.V + 1), dt.c2, dt.c1);
 	for (int i = p0 + (int)threadIdx.x; i < p1; i += kBoundsThreads) {
 		const float4 p = src[i];
 		const float rx = R0.r[0] * p.x + R0.r[1] * p.y + R0.r[2] * p.z;
@@ -268,9 +273,9 @@ __device__ __forceinline__ void lean_points(const float4* __restrict__ src, int 
 		              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
 		float worst = INFINITY;
 #pragma unroll
-		for (int k = 0; k < 6; k++) worst = fminf(worst, fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1));
+		for (int k = 0; k < 6; k++) worst = fminf(worst, fabsf(F[k] - rintf(F[k])));
 		int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
-		if (worst <= 0.f) {
+		if (worst <= eps_grid) {
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
 				ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
@@ -302,9 +307,14 @@ __device__ __forceinline__ void lean_points(const float4* __restrict__ src, int 
 				const f2 v = f2{*reinterpret_cast<const float*>(gb + (fx[0] + yz)), *reinterpret_cast<const float*>(gb + (fx[1] + yz))};
 #pragma unroll
 				for (int q = 0; q < NP; q++) {
-					const f2 mm = __builtin_elementwise_max(v - f2{rho[q], rho[q]}, f2{0.f, 0.f});
+					f2 vq = v, mm = v;
+					if (!(LAST_ZERO && q == NP - 1)) {
+						vq = v - f2{rho[q], rho[q]};
+						mm = __builtin_elementwise_max(vq, f2{0.f, 0.f});
+					}
 					ub2[q][k] = ub2[q][k] + mm * mm;
-					const f2 dis = __builtin_elementwise_max(mm - delta2, f2{0.f, 0.f});
+					// max(mm - delta, 0) == max(vq - delta, 0) bit for bit (delta >= 0: vq < 0 gives 0 either way, vq >= 0 is mm; x + (-d) is x - d)
+					const f2 dis = __builtin_elementwise_max(vq + ndelta2, f2{0.f, 0.f});
 					lb2[q][k] = lb2[q][k] + dis * dis;
 				}
 			}
@@ -441,7 +451,7 @@ __device__ __forceinline__ void bounds_work(
 #pragma unroll
 					for (int k = 0; k < 4; k++) { ub2[q][k] = f2{0.f, 0.f}; lb2[q][k] = f2{0.f, 0.f}; }
 				const float co[2] = {coeff, 0.f};
-				lean_points<LAYOUT, 2>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
+				lean_points<LAYOUT, 2, true>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
 #pragma unroll
 				for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[1][k].x; ub[2 * k + 1] = ub2[1][k].y; lb[2 * k] = lb2[1][k].x; lb[2 * k + 1] = lb2[1][k].y; }
 				bounds_item_store(ub, lb, twin, chunk, chunks, B, scratch, ub_out, lb_out, red);
@@ -453,7 +463,8 @@ __device__ __forceinline__ void bounds_work(
 #pragma unroll
 				for (int k = 0; k < 4; k++) { ub2[0][k] = f2{0.f, 0.f}; lb2[0][k] = f2{0.f, 0.f}; }
 				const float co[1] = {coeff};
-				lean_points<LAYOUT, 1>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
+				if (coeff == 0.f) lean_points<LAYOUT, 1, true>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);       // block-uniform: one expansion per workgroup
+				else lean_points<LAYOUT, 1, false>(src, p0, p1, dt, R0, ts, delta, co, ub2, lb2);
 #pragma unroll
 				for (int k = 0; k < 4; k++) { ub[2 * k] = ub2[0][k].x; ub[2 * k + 1] = ub2[0][k].y; lb[2 * k] = lb2[0][k].x; lb[2 * k + 1] = lb2[0][k].y; }
 			}
@@ -538,6 +549,13 @@ __host__ __device__ inline void tile_shape(int nseg, int N, int grid, int* chunk
 // (x-siblings) in packed fp32 (v_pk_add / v_pk_mul -- same per-element operations and order as the scalar code:
 // bit-identical).  Round 2's form computed brick offsets with a bounds check per axis and child (42 + 16 of its ~180
 // vector instructions per point and lane, plus the branches around eight inlined global fallbacks).
+__device__ __forceinline__ int add3(int a, int b, int c)
+{
+	int r;
+	__asm__("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
 template <bool QUEUED>
 __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restrict__ src, int N, DtDesc dt, const Rot9* __restrict__ rots,
                                                           const ParentRec* __restrict__ parents, const TileSeg* __restrict__ segs, int nseg_host, int chunks_host,
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 	f2 ub2[4], lb2[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++) { ub2[k] = f2{0.f, 0.f}; lb2[k] = f2{0.f, 0.f}; }
-	const f2 delta2 = f2{delta, delta};
+	const f2 delta2 = f2{delta, delta}, ndelta2 = f2{-delta, -delta};
 	const int p0 = chunk * chunk_pts, p1 = p0 + chunk_pts < N ? p0 + chunk_pts : N;
 	__syncthreads();
 	for (int s0 = p0; s0 < p1; s0 += kTilePatch) {
@@ -654,8 +672,14 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 			if (fast) {
 				// byte address in the tile = 4 (ix - x0) + 4 DX (iy - y0) + 4 DX DY (iz - z0)
 				const int sy = 4 * DX, sz = 4 * DX * DY;
-				const int cx = -4 * x0, cy = -sy * y0, cz = -sz * z0;
+				const int cxyz = -4 * x0 - sy * y0 - sz * z0;
+				const float eps_box = __fmaf_rn((float)dt.V, dt.c2, dt.c1);
 				const char* tb = reinterpret_cast<const char*>(tile);
+				// A segment is one search: all its lanes make the same pass.  In the upper-bound pass (coeff == 0, jly_goicp.cpp:284-285 with
+				// maxRotDis = 0) the residual is the looked-up distance itself: v - 0 and max(v, 0) are v bit for bit (the DT holds no negative
+				// value), so that pass runs a loop without the subtraction and the clamp (12 of ~90 vector instructions per point).
+				auto patch_points = [&](auto ub_pass) {
+				constexpr bool UB_PASS = decltype(ub_pass)::value;
 				for (int j = wave + 4 * sub; j < np; j += 4 * L) {
 					const float4 q = rp[j];                               // one address per lane group: a broadcast read
 					const float qx[2] = {q.x + ts.tx0, q.x + ts.tx1}, qy[2] = {q.y + ts.ty0, q.y + ts.ty1}, qz[2] = {q.z + ts.tz0, q.z + ts.tz1};
@@ -664,12 +688,14 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 					float F[6] = {__fmaf_rn(qx[0] - dt.xmin_f, dt.scale_f, 0.5f), __fmaf_rn(qx[1] - dt.xmin_f, dt.scale_f, 0.5f),
 					              __fmaf_rn(qy[0] - dt.ymin_f, dt.scale_f, 0.5f), __fmaf_rn(qy[1] - dt.ymin_f, dt.scale_f, 0.5f),
 					              __fmaf_rn(qz[0] - dt.zmin_f, dt.scale_f, 0.5f), __fmaf_rn(qz[1] - dt.zmin_f, dt.scale_f, 0.5f)};
+					// (the box lies inside the grid, so 0 <= F < V on this path: ONE bound eps(V) >= eps(F) serves all six -- a few more lanes take the
+					// exact branch, none takes a wrong index; 16 instead of 29 instructions for the test)
 					float margin[6];
 #pragma unroll
-					for (int k = 0; k < 6; k++) margin[k] = fabsf(F[k] - rintf(F[k])) - __fmaf_rn(fabsf(F[k]), dt.c2, dt.c1);
+					for (int k = 0; k < 6; k++) margin[k] = fabsf(F[k] - rintf(F[k]));
 					const float worst = fminf(fminf(fminf(margin[0], margin[1]), fminf(margin[2], margin[3])), fminf(margin[4], margin[5]));
 					int ix[2] = {(int)F[0], (int)F[1]}, iy[2] = {(int)F[2], (int)F[3]}, iz[2] = {(int)F[4], (int)F[5]};
-					if (worst <= 0.f) {
+					if (worst <= eps_box) {
 #pragma unroll
 						for (int k = 0; k < 2; k++) {
 							ix[k] = voxel_exact(qx[k], dt.xmin, dt.scale);
@@ -677,22 +703,30 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 							iz[k] = voxel_exact(qz[k], dt.zmin, dt.scale);
 						}
 					}
-					const int ax[2] = {4 * ix[0] + cx, 4 * ix[1] + cx};
-					const int ay[2] = {__mul24(iy[0], sy) + cy, __mul24(iy[1], sy) + cy};
-					const int az[2] = {__mul24(iz[0], sz) + cz, __mul24(iz[1], sz) + cz};
+					// the three origin terms ride on the x part; one three-operand add per child (the compiler would share y + z sums: 12 adds for 8)
+					const int ax[2] = {4 * ix[0] + cxyz, 4 * ix[1] + cxyz};
+					const int ay[2] = {__mul24(iy[0], sy), __mul24(iy[1], sy)};
+					const int az[2] = {__mul24(iz[0], sz), __mul24(iz[1], sz)};
 					const float rho = coeff * q.w;
 					const f2 rho2 = f2{rho, rho};
 #pragma unroll
 					for (int k = 0; k < 4; k++) {                         // pair k: children 2k (x0) and 2k + 1 (x1) of y[(k & 1)], z[(k >> 1)]
-						const int yz = ay[k & 1] + az[k >> 1];
-						f2 v = f2{*reinterpret_cast<const float*>(tb + (ax[0] + yz)), *reinterpret_cast<const float*>(tb + (ax[1] + yz))};
-						v = v - rho2;
-						const f2 m = __builtin_elementwise_max(v, f2{0.f, 0.f});
+						f2 v = f2{*reinterpret_cast<const float*>(tb + add3(ax[0], ay[k & 1], az[k >> 1])), *reinterpret_cast<const float*>(tb + add3(ax[1], ay[k & 1], az[k >> 1]))};
+						f2 m = v;
+						if constexpr (!UB_PASS) {
+							v = v - rho2;
+							m = __builtin_elementwise_max(v, f2{0.f, 0.f});
+						}
 						ub2[k] = ub2[k] + m * m;
-						const f2 dis = __builtin_elementwise_max(m - delta2, f2{0.f, 0.f});
+						// max(m - delta, 0) == max(v - delta, 0) bit for bit (delta >= 0: v < 0 gives 0 either way, v >= 0 is m), and the
+						// subtraction no longer waits for the clamp (a packed subtract of the packed difference)
+						const f2 dis = __builtin_elementwise_max(v + ndelta2, f2{0.f, 0.f});      // x + (-d) is x - d bit for bit
 						lb2[k] = lb2[k] + dis * dis;
 					}
 				}
+				};
+				if (__builtin_amdgcn_readfirstlane(__float_as_int(coeff)) == 0 && coeff == 0.f) patch_points(std::true_type{});
+				else patch_points(std::false_type{});
 			} else {
 				// the box is too large for the tile, or reaches over the edge of the grid: the direct kernel's sibling path (eight
 				// gathers in flight per point, out-of-grid extension included) -- same per-point expressions

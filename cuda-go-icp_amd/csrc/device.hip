@@ -657,9 +657,13 @@ __global__ __launch_bounds__(256) void bounds_tile_kernel(const float4* __restri
 			const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
 			const int nbx = DX >> 2, nby = ((y0 + DY - 1) >> 2) - by0 + 1, nbz = ((z0 + DZ - 1) >> 2) - bz0 + 1;
 			const int n4 = nbx * nby * nbz * 16;
+			// brick number -> (bx, by, bz) without integer division (two of them cost ~50 instructions per 16-byte piece): the quotient of b + 0.5 by
+			// a count n < 64 in float is exact for b < 2^21 -- it is at least 0.5 / n away from an integer, the rounding errors stay below that
+			const float rnbx = 1.0f / (float)nbx, rnby = 1.0f / (float)nby;
 			for (int idx = threadIdx.x; idx < n4; idx += 256) {
 				const int b = idx >> 4, part = idx & 15;
-				const int bx = b % nbx, t2 = b / nbx, by = t2 % nby, bz = t2 / nby;
+				const int t2 = (int)(((float)b + 0.5f) * rnbx), bx = b - t2 * nbx;
+				const int bz = (int)(((float)t2 + 0.5f) * rnby), by = t2 - bz * nby;
 				const int y = (by0 + by) * 4 + (part & 3) - y0, z = (bz0 + bz) * 4 + (part >> 2) - z0;
 				const size_t gb = ((size_t)(bz0 + bz) * dt.VB + (by0 + by)) * dt.VB + (bx0 + bx);
 				const float4 v = reinterpret_cast<const float4*>(dt.grid)[gb * 16 + part];

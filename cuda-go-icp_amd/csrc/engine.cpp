@@ -164,6 +164,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	{ const char* e = std::getenv("GOICP_LANES"); if (e) lanes_ = std::atoi(e); }                                  // tuning only (tools/lanes_probe.py)
 	{ const char* e = std::getenv("GOICP_LANE_MIN"); if (e) lane_min_searches_ = std::max(2, std::atoi(e)); }
 	{ const char* e = std::getenv("GOICP_LANE_MIN_WORK"); if (e) lane_min_work_ = std::atof(e); }
+	{ const char* e = std::getenv("GOICP_TILE_STICKY_SHARE"); if (e) tile_sticky_share_ = std::atof(e); }
 	{ const char* e = std::getenv("GOICP_AUTO_LANES"); if (e) auto_lanes_ = std::min(kMaxLanes, std::max(2, std::atoi(e))); }
 
 	h_target_.assign(target, target + 3 * M);
@@ -1302,7 +1303,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		// batch by what a search can list in them (1, 8, 64 .. nodes), later ones by what the last read-back saw
 		r.round_cap = (long long)Sl;
 		r.sort_round = L.sort.order != nullptr;
-		r.qp.tile_on = r.tiles && p_.lds_tiles == 1 ? 1 : 0;
+		r.qp.tile_on = r.tiles && (p_.lds_tiles == 1 || (p_.lds_tiles == 2 && tile_sticky_)) ? 1 : 0;
 		L.tile_hint_seen = 0;
 	}
 	// One chunk of rounds of a lane: queue kernel + (sort) + bound evaluation(s) per round, then the control block's read-back.
@@ -1349,7 +1350,9 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	auto adapt = [&](Run& r, const QCtl& c) {
 		QLane& L = *r.L;
 		QParams& qp = r.qp;
-		if (r.tiles && p_.lds_tiles == 2) { qp.tile_on = c.tile_hint != L.tile_hint_seen ? 1 : 0; L.tile_hint_seen = c.tile_hint; }
+		// (a batch that follows one that used the tile list keeps it on for all of its rounds: an idle tile launch costs a few microseconds, a
+		// qualifying search sent through the gather list costs 1.6x per cube bound -- prove-the-optimum bunny 5.18 -> 5.0 s)
+		if (r.tiles && p_.lds_tiles == 2) { qp.tile_on = (c.tile_hint != L.tile_hint_seen || tile_sticky_) ? 1 : 0; L.tile_hint_seen = c.tile_hint; }
 		// (later rounds of a batch are narrow -- their expansions lie close together whatever the order -- and in long registrations the three
 		// extra launches per round are not free on the host side: mse 1e-4 bunny 295 vs 302 ms with the sort queued in every wide round)
 		r.sort_round = L.sort.order != nullptr && c.n_groups[r.last] >= L.sort.min_groups && r.rounds_done < 7;
@@ -1406,6 +1409,14 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		int rounds = 1;
 		for (int li = 0; li < nl; li++) rounds = std::max(rounds, run[li].rounds_done);
 		last_round_work_ = (double)cubes / kGroup / rounds * (double)N_;
+	}
+	{
+		long long tile_total = 0, all = 0;
+		for (int li = 0; li < nl; li++) {
+			tile_total += run[li].L->h_ctl->tile_total;
+			for (size_t i = 0; i < run[li].idx.size(); i++) all += run[li].L->h_search[i].cubes;
+		}
+		tile_sticky_ = tile_total > 0 && (double)tile_total * kGroup >= tile_sticky_share_ * (double)all;
 	}
 	for (int li = 0; li < nl; li++) {
 		const QLane& L = *run[li].L;
@@ -1627,7 +1638,7 @@ void Engine::register_begin()
 	early_exit_ = converged_ = false;
 	rot_ramp_ = 8;
 	late_icp_.clear(); batches_done_ = 0;
-	last_round_work_ = 0;      // every registration starts single-lane (determinism: the choice depends on this registration only)
+	last_round_work_ = 0; tile_sticky_ = false;      // every registration starts single-lane (determinism: the choice depends on this registration only)
 	{ const char* e = std::getenv("GOICP_ICP_DELAY_BATCHES"); icp_delay_ = e ? std::max(0, std::atoi(e)) : 0; }
 	icp_ms_ = 0; t_submit_ = t_wait_ = t_collect_ = 0;
 	std::memset(level_hist_, 0, sizeof(level_hist_));

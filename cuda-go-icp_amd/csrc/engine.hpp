@@ -300,6 +300,8 @@ private:
 	int lanes_ = 0, lane_min_searches_ = 64;                // Params::lanes / lane_min_searches (env GOICP_LANES / GOICP_LANE_MIN override, tuning only)
 	bool tiles_usable() const;
 	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration
+	double tile_sticky_share_ = 0.5;      // ... when at least this share of the previous batch's cube bounds came from tiles (env GOICP_TILE_STICKY_SHARE, tuning only)
+	bool tile_sticky_ = false;            // lds_tiles == 2: the previous batch evaluated expansions from tiles -> this batch launches the tile list in every round
 	long long tile_rounds_ = 0;           // rounds whose tile evaluation was launched
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;
 	// icp staging

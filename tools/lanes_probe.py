@@ -22,8 +22,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         t0 = time.perf_counter(); eng.run(); ts.append(time.perf_counter() - t0)
     c = eng.counters
     t = float(np.median(ts[1:])) if len(ts) > 2 else min(ts)
-    print("%-8s %s mse %g lanes %s min %s work %s auto-lanes %s: %9.2f ms  cube bounds %d  rot nodes %d  rounds %d  icp %d  sse %.7g  R00 %.7f" % (
-        which, os.environ.get('GOICP_PROBE_KW', ''), mse, os.environ.get("GOICP_LANES", "default"), os.environ.get("GOICP_LANE_MIN", "default"), os.environ.get("GOICP_LANE_MIN_WORK", "default"), os.environ.get("GOICP_AUTO_LANES", "default"), 1e3 * t, c.cubes, c.rot_pops, c.bounds_launches, c.icp_iters,
+    print("%-8s %s mse %g lanes %s min %s work %s auto-lanes %s: %9.2f ms  cube bounds %d  rot nodes %d  rounds %d  tiles %.0f %%  icp %d  sse %.7g  R00 %.7f" % (
+        which, os.environ.get('GOICP_PROBE_KW', ''), mse, os.environ.get("GOICP_LANES", "default"), os.environ.get("GOICP_LANE_MIN", "default"), os.environ.get("GOICP_LANE_MIN_WORK", "default"), os.environ.get("GOICP_AUTO_LANES", "default"), 1e3 * t, c.cubes, c.rot_pops, c.bounds_launches, 800.0 * c.tile_expansions / max(c.cubes, 1), c.icp_iters,
         eng.get_best_error(), eng.optR[0, 0]), flush=True)
 else:
     sets = [a for a in sys.argv[1:] if ":" in a] or ["1:64", "2:64", "0:64"]

@@ -287,7 +287,8 @@ def main():
     ap.add_argument("--workload", default="bunny", choices=["bunny", "s1", "s2"],
                     help="bunny = BASELINE configs[1] (default); s1 = synthetic 40k/40k V=300; s2 = synthetic 1M/1M V=512 (configs[4] per GPU)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded end-to-end registration when N > 1")
-    ap.add_argument("--sharded-timeout", type=int, default=150, help="watchdog of the sharded leg, seconds")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="watchdog of the sharded leg, seconds")
+    ap.add_argument("--no-s2-sharded", action="store_true", help="skip the sharded registration of the 1 M-point configuration (BASELINE configs[4]) when N > 1")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL; one GPU per rank) | gloo (rehearsal: all ranks on GPU 0)")
     ap.add_argument("--shard-ramp", type=int, default=32, help="sharded legs: a rank's step follows the single-GPU driver's ramp of rotation parents per batch, 8 -> this (0 = a fixed 8 per step)")
     ap.add_argument("--deep-mse", type=float, default=3e-5, help="mse threshold of the deep strong-scaling leg (bunny; below the optimum's error: the search has to PROVE the optimum, 6.7 s on one GPU); 0 = skip")
@@ -714,8 +715,8 @@ def main():
                 ramp = max(0, args.shard_ramp)
                 step_rule = "8 rotation parents in the first step, doubling per step up to %d (the single-GPU driver's ramp), one exchange per batch" % ramp if ramp > 8 else "8 rotation parents per step"
 
-                def one(t_cloud, s_cloud, mse, stale):
-                    eng = pkg.FastGoICP(t_cloud, s_cloud, mse, dt_size=300, device=local_rank)
+                def one(t_cloud, s_cloud, mse, stale, dt_size=300):
+                    eng = pkg.FastGoICP(t_cloud, s_cloud, mse, dt_size=dt_size, device=local_rank)
                     dist.barrier()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
@@ -764,6 +765,36 @@ def main():
                                "parallel_efficiency": round(wall1 / d_["wall_s"] / world, 3),
                                "same_optimum": bool(abs(d_["sse"] - sse1) <= 1e-3 * max(sse1, 1e-6) + d_["sse_threshold"])})
                     res["deep"] = d_
+                if not args.no_s2_sharded:
+                    # BASELINE configs[4]: the synthetic 1 M x 1 M cloud on a 512^3 DT (537 MB, HBM-resident), full SE(3) BnB, sharded.  The variant the
+                    # parity test registers (tests/test_gpu_parity.py test_s2_fullsize): relief 0.15 and mse = 1.2 x the measured noise floor of the true
+                    # pose, so that the outer BnB has to work (128 rotation nodes, ~1 400 ICP iterations of ~1 ms: an ICP-dominated registration --
+                    # every rank refines its own candidates, the ICP loop does not shard -- hence a latency / replication case, not the scaling one)
+                    from cuda_go_icp_amd import synth
+                    s2t, s2s, s2R, s2tt = synth.make_pair(seed=synth.S2["seed"], M=synth.S2["M"], N=synth.S2["N"], amp=0.15)
+                    w2 = torch.zeros(6, dtype=torch.float64, device=dev)
+                    if rank == 0:
+                        e2 = pkg.FastGoICP(s2t, s2s, 1e-3, dt_size=synth.S2["V"], device=local_rank)
+                        floor = float(e2.registration.compute_sse_error(s2R, s2tt)) / len(s2s)
+                        e2.registration.close()
+                        e2 = pkg.FastGoICP(s2t, s2s, 1.2 * floor, dt_size=synth.S2["V"], device=local_rank)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        e2.run()
+                        w2[0] = time.perf_counter() - t1
+                        c2 = e2.counters
+                        w2[1], w2[2], w2[3], w2[4], w2[5] = float(c2.cubes), float(c2.rot_pops), float(e2.get_best_error()), float(c2.icp_iters), floor
+                        e2.registration.close()
+                    dist.broadcast(w2, src=0)
+                    floor = float(w2[5].item())
+                    r2, R2, t2 = one(s2t, s2s, 1.2 * floor, False, dt_size=synth.S2["V"])
+                    ang2 = float(2 * np.arcsin(min(1.0, np.linalg.norm(R2.astype(np.float64) - s2R) / (2 * np.sqrt(2)))))
+                    r2.update({"workload": "BASELINE configs[4]: synthetic N=M=1000000, DT 512^3 (537 MB), relief 0.15, mse = 1.2 x the measured floor of the true pose (%.3g) -- the parity test's registration; ICP-dominated" % floor,
+                               "rot_error_rad_vs_ground_truth": round(ang2, 5), "trans_error_vs_ground_truth": round(float(np.linalg.norm(t2 - s2tt)), 5),
+                               "tolerance": "3e-2 rad / 1e-2 (tests/test_gpu_parity.py test_s2_fullsize: flat landscape at 1.2 x floor)",
+                               "world1": {"wall_s": round(float(w2[0].item()), 4), "cube_bounds": int(w2[1].item()), "rot_pops": int(w2[2].item()), "sse": float(w2[3].item()), "icp_iters": int(w2[4].item())},
+                               "speedup_vs_world1": round(float(w2[0].item()) / max(r2["wall_s"], 1e-9), 3)})
+                    res["s2"] = r2
                 if args.backend == "nccl":
                     B.check(lib.goicp_rccl_comm_destroy(C.byref(comm)))
                 box['res'] = res

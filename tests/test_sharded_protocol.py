@@ -257,3 +257,7 @@ def test_bench_plain_launch_two_ranks_gloo():
     assert "error" not in sh and "error" not in sh["spanner"] and sh["spanner"]["bulk_synchronous"]["sse"] < sh["spanner"]["bulk_synchronous"]["sse_threshold"]
     d = sh["deep"]
     assert d["same_optimum"] and d["world1"]["cube_bounds"] > 0 and 0.5 < d["work_inflation"] < 2.0 and d["speedup_vs_world1"] > 0
+    # BASELINE configs[4] sharded: the 1 M-point registration of test_s2_fullsize, same tolerance against the ground truth
+    s2 = sh["s2"]
+    assert s2["sse"] < s2["sse_threshold"] and s2["rot_error_rad_vs_ground_truth"] <= 3e-2 and s2["trans_error_vs_ground_truth"] <= 1e-2
+    assert s2["world1"]["rot_pops"] >= 50 and s2["rot_pops_all_ranks"] >= 50

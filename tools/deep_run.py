@@ -19,7 +19,8 @@ data = np.fromfile(os.path.join(g, "data_bunny.f32"), dtype="<f4").reshape(-1, 3
 mse = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-5
 kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2:]}
 eng = pkg.FastGoICP(model, data, mse, **kw)
-t0 = time.perf_counter(); eng.run(); wall = time.perf_counter() - t0
+for _ in range(int(os.environ.get("DEEP_RUN_REPEATS", "1"))):
+    t0 = time.perf_counter(); eng.run(); wall = time.perf_counter() - t0
 c = eng.counters
 print("mse %g %s: %.3f s  sse %.6f  cube bounds %d  from tiles %.1f %%  rot nodes %d  rounds %d  lane batches %d" % (
     mse, kw, wall, eng.get_best_error(), c.cubes, 800.0 * c.tile_expansions / c.cubes, c.rot_pops, c.bounds_launches, c.lane_batches), flush=True)

@@ -36,7 +36,7 @@ class CParams(C.Structure):
                 ("use_rot_range", C.c_int32), ("use_trans_range", C.c_int32), ("rot_min", C.c_float * 3), ("rot_max", C.c_float * 3),
                 ("trans_min", C.c_float * 3), ("trans_max", C.c_float * 3), ("rot_search_depth", C.c_int32), ("trans_search_depth", C.c_int32),
                 ("icp_fused", C.c_int32), ("bounds_fp16", C.c_int32), ("icp_nn_cache", C.c_int32), ("flow", C.c_int32), ("adaptive_k", C.c_int32), ("queue_cap", C.c_int32), ("device_queues", C.c_int32),
-                ("lds_tiles", C.c_int32), ("tile_spread_vox", C.c_float), ("tile_min", C.c_int32), ("stale_widen", C.c_int32), ("ub_tiebreak", C.c_int32), ("icp_point_seed", C.c_int32), ("ub_share", C.c_float), ("twin_fusion", C.c_int32), ("sort_items", C.c_int32), ("stale_compact", C.c_int32), ("stream_priority", C.c_int32), ("lanes", C.c_int32), ("lane_min_searches", C.c_int32), ("icp_lane_walk", C.c_int32)]
+                ("lds_tiles", C.c_int32), ("tile_spread_vox", C.c_float), ("tile_min", C.c_int32), ("stale_widen", C.c_int32), ("ub_tiebreak", C.c_int32), ("icp_point_seed", C.c_int32), ("ub_share", C.c_float), ("twin_fusion", C.c_int32), ("sort_items", C.c_int32), ("stale_compact", C.c_int32), ("stream_priority", C.c_int32), ("lanes", C.c_int32), ("lane_min_searches", C.c_int32)]
 
 
 class CCube(C.Structure):

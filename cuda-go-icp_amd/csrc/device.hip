@@ -1767,207 +1767,6 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// One query per LANE (round 4): the pass for clouds above kIcpStridedMaxN points, where the cooperative walker above is bound by VALU issue
-// (1 244 vector instructions per wavefront of FOUR queries: a 64-ary group costs 64 box tests however few of them matter).  Here a lane walks
-// the same tree as a 4-ary hierarchy (Bvh4Desc) by itself: a node is six 16-byte loads and four box tests, the walk keeps no stack -- the tree
-// is implicit, so a lane remembers only, per level, which of the four children it still has to enter (4 bits x <= 9 levels) and finds its
-// way back by shifting the node index.  Neighbouring source points (k-d order) walk nearly the same path, so the wavefront's loads coalesce
-// and its lanes stay in step.  Exactness is the cooperative walker's: a child is entered unless its box distance (box_lb1, the same
-// monotone expression) EXCEEDS the best distance, leaves are scanned whole with the lowest original index winning ties, the walk starts from
-// the same candidate (the nearest-point table), and the sums take the same route: per 16 consecutive queries a float sum in query order,
-// turned into fixed point, added as integers -- so an ICP run is bit-identical to the cooperative pass's.
-// ------------------------------------------------------------------------------------------------
-size_t bvh4_nodes(int D)
-{
-	const int T = D <= 0 ? 1 : (D + 1) / 2, shift0 = D <= 0 ? 0 : (D & 1 ? 1 : 2);
-	size_t n = 1, level = 1;
-	for (int t = 1; t < T; t++) { level <<= (t == 1 ? shift0 : 2); n += level; }
-	return n;
-}
-
-__global__ void bvh4_build_kernel(KdDesc kd, float4* __restrict__ nodes, unsigned off, unsigned count, int shift, long long child_off)
-{
-	const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= count) return;
-	float lo[3][4], hi[3][4];
-#pragma unroll
-	for (int c = 0; c < 4; c++) {
-#pragma unroll
-		for (int k = 0; k < 3; k++) { lo[k][c] = INFINITY; hi[k][c] = -INFINITY; }
-		if (c < (1 << shift)) {
-			const unsigned child = (j << shift) + (unsigned)c;
-			if (child_off < 0) {            // a leaf: its box is child (child & 63) of group (child >> 6) of the hierarchy's last level
-				const float* rec = kd.boxes[kd.K - 1] + (size_t)(child >> 6) * 384;
-#pragma unroll
-				for (int k = 0; k < 3; k++) { lo[k][c] = rec[64 * k + (child & 63u)]; hi[k][c] = rec[192 + 64 * k + (child & 63u)]; }
-			} else {
-				const float4* r = nodes + ((size_t)child_off + child) * 6;
-#pragma unroll
-				for (int k = 0; k < 3; k++) {
-					const float4 a = r[k], b = r[3 + k];
-					lo[k][c] = fminf(fminf(a.x, a.y), fminf(a.z, a.w));
-					hi[k][c] = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w));
-				}
-			}
-		}
-	}
-	float4* dst = nodes + ((size_t)off + j) * 6;
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		dst[k] = make_float4(lo[k][0], lo[k][1], lo[k][2], lo[k][3]);
-		dst[3 + k] = make_float4(hi[k][0], hi[k][1], hi[k][2], hi[k][3]);
-	}
-}
-
-hipError_t launch_bvh4_build(const KdDesc& kd, int D, float4* nodes, Bvh4Desc* out, hipStream_t stream)
-{
-	if (D < 0 || D > 6 * kMaxLevels || !nodes || !out) return hipErrorInvalidValue;
-	const int T = D <= 0 ? 1 : (D + 1) / 2, shift0 = D <= 0 ? 0 : (D & 1 ? 1 : 2);
-	unsigned cnt[16], off[16];
-	cnt[0] = 1; off[0] = 0;
-	for (int t = 1; t < T; t++) { cnt[t] = cnt[t - 1] << (t == 1 ? shift0 : 2); off[t] = off[t - 1] + cnt[t - 1]; }
-	for (int t = T - 1; t >= 0; t--) {
-		const int shift = t == 0 ? shift0 : 2;
-		hipLaunchKernelGGL(bvh4_build_kernel, dim3((cnt[t] + 255) / 256), dim3(256), 0, stream, kd, nodes, off[t], cnt[t], shift, t == T - 1 ? -1ll : (long long)off[t + 1]);
-	}
-	out->nodes = nodes; out->T = T; out->shift0 = shift0;
-	return hipGetLastError();
-}
-
-constexpr int kLaneThreads = 256;
-template <int LAYOUT>
-__global__ __launch_bounds__(kLaneThreads) void icp_pass_lane_kernel(const float4* __restrict__ src, int N, IcpState* __restrict__ st, KdDesc kd, Bvh4Desc bv, DtDesc dt,
-                                                                      unsigned long long* __restrict__ acc)
-{
-	__shared__ float red[kLaneThreads][kIcpAcc + 1];           // + 1: the 16 queries of a group sit 17 words apart (no bank conflict in the column sums)
-	__shared__ long long gsum[kLaneThreads / 16][kIcpAcc];
-	const int i = blockIdx.x * kLaneThreads + threadIdx.x;
-	const bool valid = i < N;
-	const float4 p = src[valid ? i : N - 1];
-	if (st->converged) return;                                 // loop already finished: queued launches drain
-	// jly_icp3d.hpp:222-224, left-to-right float sums
-	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-	float best, mx = 0.f, my = 0.f, mz = 0.f;
-	int idx = INT_MAX;
-	if (dt.nn_ids) {
-		// the cooperative walker's start (rows_nearest): a real candidate from the nearest-point table
-		const int V1 = dt.V - 1;
-		const int ix = min(max((int)rintf((qx - dt.xmin_f) * dt.scale_f), 0), V1);
-		const int iy = min(max((int)rintf((qy - dt.ymin_f) * dt.scale_f), 0), V1);
-		const int iz = min(max((int)rintf((qz - dt.zmin_f) * dt.scale_f), 0), V1);
-		size_t off;
-		if (LAYOUT == 0) off = ((size_t)iz * dt.V + iy) * dt.V + ix;
-		else off = (((size_t)(iz >> 2) * dt.VB + (iy >> 2)) * dt.VB + (ix >> 2)) * 64 + (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3));
-		const float4 pt = kd.pts[dt.nn_ids[off]];
-		const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
-		float e = d0 * d0;                                     // the leaf scan's accumulation order: the same bits
-		e += d1 * d1;
-		e += d2 * d2;
-		best = e; idx = __float_as_int(pt.w); mx = pt.x; my = pt.y; mz = pt.z;
-	} else
-		best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
-	// ---- the walk: (t, j) = level and index of the node whose children are looked at; off / cnt = first node and node count of level t ----
-	int t = 0;
-	unsigned j = 0, off = 0, cnt = 1;
-	unsigned long long todo = 0;                               // 4 bits per level: children still to enter
-	bool active = valid;
-	while (active) {
-		const int sh = t == 0 ? bv.shift0 : 2;
-		const float4* r = bv.nodes + ((size_t)off + j) * 6;
-		const Box6x4 b{r[0], r[1], r[2], r[3], r[4], r[5]};
-		float lb[4];
-		boxes_lb4(b, qx, qy, qz, lb);
-		unsigned m = (lb[0] <= best ? 1u : 0u) | (lb[1] <= best ? 2u : 0u) | (lb[2] <= best ? 4u : 0u) | (lb[3] <= best ? 8u : 0u);
-		if (t + 1 == bv.T) {
-			// the children are leaves: scan those still within the best distance (it shrinks as they are scanned), nearest box first is not
-			// needed -- the candidate the walk started from is nearly always the neighbour already
-#pragma unroll 1
-			for (int c = 0; c < 4; c++) {
-				if (!((m >> c) & 1u) || !(lb[c] <= best)) continue;
-				const float4* lp = kd.pts + ((size_t)((j << sh) + (unsigned)c)) * kLeafSlots;
-#pragma unroll
-				for (int s0 = 0; s0 < kLeafSlots; s0 += 4) {
-					float4 pq[4];
-#pragma unroll
-					for (int s = 0; s < 4; s++) pq[s] = lp[s0 + s];
-#pragma unroll
-					for (int s = 0; s < 4; s++) {
-						const float d0 = qx - pq[s].x, d1 = qy - pq[s].y, d2 = qz - pq[s].z;
-						float e = d0 * d0;                             // L2_Simple_Adaptor accumulation order
-						e += d1 * d1;
-						e += d2 * d2;
-						const int id = __float_as_int(pq[s].w);
-						if (e < best || (e == best && id < idx)) { best = e; idx = id; mx = pq[s].x; my = pq[s].y; mz = pq[s].z; }
-					}
-				}
-			}
-			m = 0u;
-		}
-		if (m) {
-			// enter the nearest of the children within reach, remember the others
-			int c = 0;
-			float lc = INFINITY;
-#pragma unroll
-			for (int k = 3; k >= 0; k--) if (((m >> k) & 1u) && lb[k] <= lc) { lc = lb[k]; c = k; }
-			m &= ~(1u << c);
-			todo = (todo & ~(15ull << (4 * t))) | ((unsigned long long)m << (4 * t));
-			off += cnt; cnt <<= sh; j = (j << sh) + (unsigned)c; t++;
-		} else {
-			// back up to the nearest level with a child left to enter
-			bool found = false;
-			while (t > 0 && !found) {
-				const int shp = t == 1 ? bv.shift0 : 2;
-				cnt >>= shp; off -= cnt; j >>= shp; t--;
-				const unsigned mm = (unsigned)(todo >> (4 * t)) & 15u;
-				if (mm) {
-					const int c = __ffs((int)mm) - 1;
-					todo &= ~(1ull << (4 * t + c));
-					off += cnt; cnt <<= shp; j = (j << shp) + (unsigned)c; t++;
-					found = true;
-				}
-			}
-			active = found;
-		}
-	}
-	// ---- the sums: the cooperative pass's route (16 consecutive queries = one of its workgroups) ----
-	{
-		float a[kIcpAcc];
-#pragma unroll
-		for (int k = 0; k < kIcpAcc; k++) a[k] = 0.f;
-		if (valid) {
-			const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
-			const float bx = mx - st->cm[0], by = my - st->cm[1], bz = mz - st->cm[2];
-			a[0] = ax; a[1] = ay; a[2] = az;
-			a[3] = bx; a[4] = by; a[5] = bz;
-			a[6] = ax * bx; a[7] = ax * by; a[8] = ax * bz;
-			a[9] = ay * bx; a[10] = ay * by; a[11] = ay * bz;
-			a[12] = az * bx; a[13] = az * by; a[14] = az * bz;
-			a[15] = best;
-		}
-#pragma unroll
-		for (int k = 0; k < kIcpAcc; k++) red[threadIdx.x][k] = a[k];
-	}
-	__syncthreads();
-	{
-		const int g = threadIdx.x >> 4, k = threadIdx.x & 15;
-		float sum = red[g * 16][k];
-#pragma unroll
-		for (int x = 1; x < 16; x++) sum += red[g * 16 + x][k];
-		gsum[g][k] = __double2ll_rn((double)sum * (double)st->acc_scale);
-	}
-	__syncthreads();
-	if (threadIdx.x < kIcpAcc) {
-		long long v = 0;
-#pragma unroll
-		for (int g = 0; g < kLaneThreads / 16; g++) v += gsum[g][threadIdx.x];
-		unsigned long long* a = acc + (size_t)(blockIdx.x & (kIcpAccReplicas - 1)) * kIcpAcc + threadIdx.x;
-		__hip_atomic_fetch_add(a, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-
 // ---- trimmed ICP (trim_fraction > 0; jly_icp3d.hpp:236-252): NN for every point, exact selection of
 // the `num` smallest squared distances (radix select, ties in point order), sums over the selected ----
 template <int K, int LAYOUT>
@@ -2623,13 +2422,8 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 
 // ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc, const Bvh4Desc* bvh)
+                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc)
 {
-	if (!ticket && acc && dt.layout && bvh && bvh->nodes && !nn_cache) {
-		hipLaunchKernelGGL(icp_pass_lane_kernel<1>, dim3((N + kLaneThreads - 1) / kLaneThreads), dim3(kLaneThreads), 0, stream, src, N, st, kd, *bvh, dt, acc);
-		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinAccThreads), 0, stream, acc, st);
-		return hipGetLastError();
-	}
 	if (!ticket && acc && dt.layout) {
 		// the default form: fixed-point sums, no rows of partial sums
 		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream);

@@ -79,18 +79,6 @@ struct KdDesc {
 	int M;
 };
 
-// The same tree as a 4-ary hierarchy for the one-query-per-lane walker (large clouds; device.hip icp_pass_lane_kernel): level t holds the
-// binary nodes of depth b_t (b_0 = 0, b_1 = shift0 in {0, 1, 2}, then + 2 per level), a node = the boxes of its <= 4 children as six float4
-// {lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4]} (empty children: inverted infinite boxes); the children of the T-th level are the
-// leaves of KdDesc::pts.  Implicit: the children of node j of level t are nodes (j << shift_t) + c of level t + 1.
-struct Bvh4Desc {
-	const float4* nodes;   // levels back to back, six float4 per node; nullptr: not built
-	int T;                 // internal levels (>= 1)
-	int shift0;            // fan-out of the root = 1 << shift0; every other level: 4
-};
-size_t bvh4_nodes(int leaves_log2);      // nodes of all levels for 2^D leaves
-hipError_t launch_bvh4_build(const KdDesc& kd, int leaves_log2, float4* nodes, Bvh4Desc* out, hipStream_t stream);
-
 struct Pose { float R[9]; float t[3]; };
 
 constexpr int kGroup = 8;          // cubes per workgroup pass (the 8 siblings of one BnB expansion)
@@ -243,10 +231,8 @@ size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_i
 // nearest; nullptr -> every query walks.
 // acc: kIcpAccReplicas x 16 zeroed 64-bit words (kept zero between iterations by the finalize) -> clouds of up to kIcpStridedMaxN
 // points sum there instead of writing a row of partial sums per workgroup; nullptr -> rows for every size
-// bvh != nullptr (with acc, a bricked DT, no ticket, no cache): the one-query-per-lane pass -- same neighbours, same sums, bit for bit
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr,
-                                const Bvh4Desc* bvh = nullptr);
+                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,

@@ -426,17 +426,6 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 		}
 		for (int l = 0; l < kMaxLevels; l++) kd_.boxes[l] = d_kd_boxes_[l];
 		kd_.pts = d_kd_pts_; kd_.M = (int)M_;
-		// the 4-ary view of the same tree for the one-query-per-lane ICP pass (a few launches over the leaf boxes; 87 k nodes = 8 MB at 1 M points)
-		lane_walk_ = p_.icp_lane_walk > 0 || (p_.icp_lane_walk < 0 && N_ > (size_t)kIcpStridedMaxN);
-		if (const char* e = std::getenv("GOICP_ICP_LANE_WALK")) lane_walk_ = std::atoi(e) != 0;       // tuning only (tools/icp_lane_probe.py)
-		if (lane_walk_ && dt_.layout == 1 && inliers_ >= (int)N_ && !p_.icp_fused && p_.icp_nn_cache == 0) {
-			int D = 0;
-			while (((size_t)kLeafSlots << D) < kd_slots_) D++;
-			if (((size_t)kLeafSlots << D) != kd_slots_) throw std::logic_error("goicp: leaf count of the k-d hierarchy is not a power of two");
-			HIPCHK(hipMalloc(&d_bvh_nodes_, sizeof(float4) * 6 * bvh4_nodes(D)));
-			HIPCHK(launch_bvh4_build(kd_, D, d_bvh_nodes_, &bvh_, stream_));
-		} else
-			lane_walk_ = false;
 	}
 	lap("k-d hierarchy + upload");
 	if (p_.icp_point_seed) {
@@ -567,7 +556,6 @@ void Engine::release()
 	hipFree(d_nn_ids_); d_nn_ids_ = nullptr;
 	for (int l = 0; l < kMaxLevels; l++) hipFree(d_kd_boxes_[l]);
 	hipFree(d_kd_pts_);
-	hipFree(d_bvh_nodes_); d_bvh_nodes_ = nullptr; bvh_ = Bvh4Desc{};
 	hipFree(d_cubes_); hipFree(d_rots_); hipFree(d_ub_); hipFree(d_lb_); hipFree(d_scratch_);
 	hipHostFree(h_cubes_); hipHostFree(h_rots_); hipHostFree(h_ub_); hipHostFree(h_lb_);
 	hipFree(d_icp_acc_); d_icp_acc_ = nullptr;
@@ -858,8 +846,7 @@ void Engine::icp_launch_one()
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
 		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
-		                            (p_.icp_nn_cache == 1 || icp_cache_active_) ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_,
-		                            lane_walk_ ? &bvh_ : nullptr));
+		                            (p_.icp_nn_cache == 1 || icp_cache_active_) ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
 }
 
 void Engine::icp_state_fetch()

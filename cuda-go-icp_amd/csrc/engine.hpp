@@ -59,8 +59,6 @@ struct Params {
 	                              // lane_min_searches inner searches is cut into lanes by rotation slot and the lanes run their lock-step rounds side by side on their own
 	                              // streams (own lists, own control block): one lane's dependent launches drain beside the others' (run_inner_device)
 	int lane_min_searches = 64;
-	int icp_lane_walk = -1;       // the one-query-per-lane ICP pass (device.hip icp_pass_lane_kernel; bit-identical to the cooperative pass): -1 = clouds above
-	                              // kIcpStridedMaxN source points (default), 0 = never, 1 = always
 	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -261,9 +259,6 @@ private:
 	double* d_overshoot_ = nullptr;
 	// k-d tree
 	KdDesc kd_{};
-	Bvh4Desc bvh_{};                  // the same tree as a 4-ary hierarchy (one-query-per-lane ICP pass); nodes == nullptr: not built
-	float4* d_bvh_nodes_ = nullptr;
-	bool lane_walk_ = false;
 	float* d_kd_boxes_[kMaxLevels] = {nullptr, nullptr, nullptr}; float4* d_kd_pts_ = nullptr;
 	// bounds staging
 	size_t cap_cubes_ = 0, cap_rots_ = 0, cap_scratch_ = 0;

@@ -107,7 +107,7 @@ void goicp_params_default(goicp_params* p)
 	}
 	p->rot_search_depth = d.rot_search_depth; p->trans_search_depth = d.trans_search_depth;
 	p->icp_fused = d.icp_fused; p->bounds_fp16 = d.bounds_fp16; p->icp_nn_cache = d.icp_nn_cache; p->flow = d.flow; p->adaptive_k = d.adaptive_k; p->queue_cap = d.queue_cap; p->device_queues = d.device_queues;
-	p->lds_tiles = d.lds_tiles; p->tile_spread_vox = d.tile_spread_vox; p->tile_min = d.tile_min; p->stale_widen = d.stale_widen; p->ub_tiebreak = d.ub_tiebreak; p->icp_point_seed = d.icp_point_seed; p->ub_share = d.ub_share; p->twin_fusion = d.twin_fusion; p->sort_items = d.sort_items; p->stale_compact = d.stale_compact; p->stream_priority = d.stream_priority; p->lanes = d.lanes; p->lane_min_searches = d.lane_min_searches; p->icp_lane_walk = d.icp_lane_walk;
+	p->lds_tiles = d.lds_tiles; p->tile_spread_vox = d.tile_spread_vox; p->tile_min = d.tile_min; p->stale_widen = d.stale_widen; p->ub_tiebreak = d.ub_tiebreak; p->icp_point_seed = d.icp_point_seed; p->ub_share = d.ub_share; p->twin_fusion = d.twin_fusion; p->sort_items = d.sort_items; p->stale_compact = d.stale_compact; p->stream_priority = d.stream_priority; p->lanes = d.lanes; p->lane_min_searches = d.lane_min_searches;
 }
 
 void goicp_params_from_config(const goicp_config* c, goicp_params* p)
@@ -151,7 +151,7 @@ int goicp_create(const goicp_params* params, const float* target_xyz, size_t n_t
 			}
 			p.rot_search_depth = params->rot_search_depth; p.trans_search_depth = params->trans_search_depth;
 			p.icp_fused = params->icp_fused; p.bounds_fp16 = params->bounds_fp16; p.icp_nn_cache = params->icp_nn_cache; p.flow = params->flow; p.adaptive_k = params->adaptive_k; p.queue_cap = params->queue_cap; p.device_queues = params->device_queues;
-			p.lds_tiles = params->lds_tiles; p.stale_widen = params->stale_widen; p.ub_tiebreak = params->ub_tiebreak; p.icp_point_seed = params->icp_point_seed; p.ub_share = params->ub_share; p.twin_fusion = params->twin_fusion; p.sort_items = params->sort_items; p.stale_compact = params->stale_compact; p.stream_priority = params->stream_priority; p.lanes = params->lanes; p.lane_min_searches = params->lane_min_searches; p.icp_lane_walk = params->icp_lane_walk;
+			p.lds_tiles = params->lds_tiles; p.stale_widen = params->stale_widen; p.ub_tiebreak = params->ub_tiebreak; p.icp_point_seed = params->icp_point_seed; p.ub_share = params->ub_share; p.twin_fusion = params->twin_fusion; p.sort_items = params->sort_items; p.stale_compact = params->stale_compact; p.stream_priority = params->stream_priority; p.lanes = params->lanes; p.lane_min_searches = params->lane_min_searches;
 			if (params->tile_spread_vox > 0.f) p.tile_spread_vox = params->tile_spread_vox;
 			if (params->tile_min > 0) p.tile_min = params->tile_min;
 		}

@@ -187,11 +187,6 @@ typedef struct goicp_params {
 	                          * lane_min_searches.  Same searches, same bounds, same result per search; measured (tools/lanes_probe.py): prove-the-optimum
 	                          * bunny 6.74 -> 5.7 s, synthetic 40 k 721 -> 649 ms, default (early-exit) registrations never qualify and are unchanged */
 	int32_t lane_min_searches; /* default 64 */
-	int32_t icp_lane_walk;   /* the ICP pass with ONE QUERY PER LANE (round 4; ICP3D::Run's neighbour search, jly_icp3d.hpp:225-234 = nanoflann's findNeighbors): a lane
-	                          * walks the target's k-d tree as a 4-ary box hierarchy by itself, without a stack (the tree is implicit: per level 4 bits of
-	                          * children still to enter).  Same neighbours (exact, lowest index on ties), same sums in the same order: an ICP run is
-	                          * bit-identical to the cooperative pass's (16 lanes per query), which is bound by instruction issue on large clouds.
-	                          * -1 (default): source clouds above 40 000 points; 0: never; 1: always */
 } goicp_params;
 
 void goicp_params_default(goicp_params* p);

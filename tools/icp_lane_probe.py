@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The one-query-per-lane ICP pass against the cooperative one (goicp_params.icp_lane_walk 0 / 1; one process per setting): ICP iterations/s over a forced
+"""(Runs at commit 994fba6 only: the lane walker was measured slower and removed -- EXPERIMENTS.md R4.15.)
+The one-query-per-lane ICP pass against the cooperative one (goicp_params.icp_lane_walk 0 / 1; one process per setting): ICP iterations/s over a forced
 200-iteration trajectory from the identity pose, a converging run, the registration, and the bits of the results (they must not differ)."""
 import os
 import subprocess

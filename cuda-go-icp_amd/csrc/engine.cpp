@@ -156,7 +156,6 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	HIPCHK(hipEventCreate(&ev1_));
 	HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
 	lane_stream_[0] = stream_; lane_stream_[1] = stream2_;
-	for (int k = 2; k < kMaxLanes; k++) HIPCHK(hipStreamCreateWithFlags(&lane_stream_[k], hipStreamNonBlocking));
 	HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
 	{ const char* e = std::getenv("GOICP_TILE_CONCURRENT"); if (e) tile_concurrent_ = std::atoi(e) != 0; }     // A/B only (tools/tile_deep.py)
@@ -1154,6 +1153,7 @@ void Engine::ensure_queues(size_t nsearch) { ensure_lane(0, nsearch); }
 void Engine::ensure_lane(int li, size_t nsearch)
 {
 	QLane& L = ql_[li];
+	if (!lane_stream_[li]) HIPCHK(hipStreamCreateWithFlags(&lane_stream_[li], hipStreamNonBlocking));     // lanes 2.. : on first use (a stream costs ~2 ms to create)
 	L.stream = lane_stream_[li];
 	if (nsearch <= L.cap) return;
 	// first use: room for a full round of the outer search (rot_batch parents x 8 children x {ub, lb} pass) -- growing in
@@ -1264,7 +1264,10 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 	if (nl == 1) { run[0].idx.resize(S); for (size_t i = 0; i < S; i++) run[0].idx[i] = (int)i; }
 	if (nl > 1) {            // the other lanes start behind the rotation upload (and everything else queued on the engine's stream)
 		HIPCHK(hipEventRecord(ev_fork_, stream_));
-		for (int li = 1; li < nl; li++) HIPCHK(hipStreamWaitEvent(lane_stream_[li], ev_fork_, 0));
+		for (int li = 1; li < nl; li++) {
+			if (!lane_stream_[li]) HIPCHK(hipStreamCreateWithFlags(&lane_stream_[li], hipStreamNonBlocking));     // lanes 2.. : on first use (a stream costs ~2 ms to create)
+			HIPCHK(hipStreamWaitEvent(lane_stream_[li], ev_fork_, 0));
+		}
 	}
 	for (int li = 0; li < nl; li++) {
 		Run& r = run[li];

@@ -35,7 +35,10 @@ cases = {# the full bunny: 460 inner searches in lock-step -- twin expansions ga
          "bunny10_flow": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-3, {"flow": 8}),
          # a registration that digs (threshold below the optimum's error): the tile list, the stale-incumbent round widening and the
          # nearest-target-point seed all take part -- and must be as reproducible as everything else
-         "bunny10_deep_tiles": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-4, {"lds_tiles": 1, "tile_spread_vox": 16.0})}
+         "bunny10_deep_tiles": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-4, {"lds_tiles": 1, "tile_spread_vox": 16.0}),
+         # every batch of at least 8 inner searches cut into four lanes (own stream, lists and control block each): the multi-stream rounds and
+         # the per-lane buffers, created and destroyed with every engine
+         "bunny10_deep_lanes": (cloud("model_bunny"), cloud("data_bunny", 10), 1e-4, {"lanes": 4, "lane_min_searches": 8})}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 ref, base = {}, None
 t0 = time.time()

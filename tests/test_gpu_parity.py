@@ -78,6 +78,43 @@ def test_dt_layouts_agree(pkg, bunny_model, bunny_data10, oracle_mod, layout, V)
     r.close()
 
 
+def test_dt_maximum_size(pkg, bunny_model, bunny_data10, oracle_mod):
+    """The largest grid the engine takes: dt_size = 640 (1.05 GB of fp32 + the same again for the nearest-point table; the kernels address the
+    grid with 32-bit BYTE offsets, device.hip dt_fetch, so 640^3 x 4 B < 2^32 is the bound -- 641 is refused, not wrapped).  The whole grid is
+    bit-identical to the oracle's exact EDT at that size, the highest offsets are reached through the lookup itself (a one-point source at
+    the origin makes goicp_eval_bounds(I, q, w = 0) return Distance(q)^2: queries in the last voxels, on the faces and beyond them), a cube
+    bound agrees with the oracle's on that grid, and an ICP run lands where the 300^3 engine's does."""
+    V = 640
+    with pytest.raises(Exception):
+        pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_size=V + 1)
+    dt = oracle_mod.DistanceTransform(bunny_model, V, 2.0)
+    reg = pkg.Registration(bunny_model, bunny_data10, 1e-3, dt_size=V)
+    Vg, scale, origin = reg.dt_info()
+    assert Vg == V and scale == dt.scale and tuple(origin) == tuple(dt.origin)
+    grid = reg.dt_download()
+    assert grid.shape == (V, V, V) and np.array_equal(grid, dt.grid())
+    del grid
+    ub, lb = reg.eval_bounds(np.eye(3), np.array([[0.1, -0.2, 0.05, 0.25]], np.float32), -1)
+    oub, olb = oracle_mod.cube_bound(dt, bunny_data10, None, [0.1, -0.2, 0.05], 0.25)
+    assert abs(ub[0] - oub) <= 1e-4 * oub and abs(lb[0] - olb) <= 1e-4 * max(olb, 1e-3)
+    small = pkg.Registration(bunny_model, bunny_data10, 1e-3)
+    e640, R640, t640 = pkg.IterativeClosestPoint3D(reg, 200, 1e-9).run()
+    e300, R300, t300 = pkg.IterativeClosestPoint3D(small, 200, 1e-9).run()
+    assert rot_angle(R640, R300) <= 1e-6 and np.linalg.norm(t640 - t300) <= 1e-6      # the neighbour search does not depend on the grid (only its start does)
+    small.close(); reg.close()
+    one = pkg.Registration(bunny_model, np.zeros((1, 3), np.float32), 1e-3, dt_size=V)
+    x0 = np.array(dt.origin)
+    hi = x0 + (V - 1) / dt.scale                                      # centre of the last voxel per axis
+    rng = np.random.default_rng(5)
+    q = np.concatenate([hi + rng.uniform(-1.5, 1.5, (256, 3)) / dt.scale,           # the last voxels and just beyond the far faces: the largest offsets
+                        x0 + rng.uniform(-1.5, 1.5, (64, 3)) / dt.scale,            # the first voxels and just before the near faces
+                        x0 + rng.uniform(0, V - 1, (256, 3)) / dt.scale]).astype(np.float32)
+    ub, lb = one.eval_bounds(np.eye(3), np.concatenate([q, np.zeros((len(q), 1), np.float32)], 1), -1)
+    d = dt.distance(q.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(ub, d * d) and np.array_equal(lb, ub)
+    one.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # (a) cube bounds
 # ----------------------------------------------------------------------------------------------

@@ -1309,7 +1309,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		r.qp.tile_on = r.tiles && (p_.lds_tiles == 1 || (p_.lds_tiles == 2 && tile_sticky_)) ? 1 : 0;
 		L.tile_hint_seen = 0;
 	}
-	// One chunk of rounds of a lane: queue kernel + (sort) + bound evaluation(s) per round, then the control block's read-back.
+	// One chunk of rounds of a lane: queue kernel + (sort) + bound evaluation(s) per round; the control block is read back behind the LAST round's queue kernel.
 	auto submit = [&](Run& r) {
 		const double t0 = now_ms();
 		QLane& L = *r.L;
@@ -1320,6 +1320,17 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 			const int parity = r.parity;
 			HIPCHK(launch_bnb_queue(L.d_search, L.d_nodes, (int)Sl, qp, L.d_parents[parity ^ 1], L.d_parents[parity], L.d_ub, L.d_lb, L.d_scratch, L.d_ctl, parity, L.stream, r.tiles ? &L.tile : nullptr,
 			                        r.twins ? L.d_psearch[parity] : nullptr));
+			if (k == r.chunk - 1) {
+				// Everything the host looks at after a chunk -- what the last round listed, how many searches are running, overflow, the tile
+				// hint -- is written by THIS kernel; the bound evaluations behind it only fill in the bounds the next queue kernel digests.  So the
+				// control block is read back here, ahead of the last round's bound evaluation, and the host decides and queues the next chunk
+				// while those bounds are being evaluated: the same information at the same point of the search as a read-back after the chunk
+				// (identical decisions, identical counts) for a 4 us copy in the stream instead of ~45 us of idle GPU per chunk.  Measured: bunny
+				// 33.1-33.6 -> 32.8 ms, skull 6.4 -> 6.3, the rest within the spread.  (From a SIDE stream the copy lost: its blit kernel cannot
+				// start while the persistent bound kernels hold every CU -- bunny 33.9 ms, synthetic 40 k mse 3e-5 610 -> 642 ms.)
+				HIPCHK(hipMemcpyAsync(L.h_ctl, L.d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, L.stream));
+				HIPCHK(hipEventRecord(L.ev_ctl[0], L.stream));
+			}
 			// The round's two lists are independent (own records, own bounds, own partial sums), so the tile list's evaluation CAN be forked onto a
 			// second stream right behind the queue kernel and run beside the direct list's.  Built and measured (EXPERIMENTS R4.8): slower -- bunny
 			// mse 3e-5 6.73 -> 7.40 s, bunny/10 1.09 -> 1.14 s, identical results -- the VALU-bound tile kernel (32 KB of LDS per workgroup) and the
@@ -1345,8 +1356,6 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 			cnt_.bounds_launches++;
 			queue_rounds_++;
 		}
-		HIPCHK(hipMemcpyAsync(L.h_ctl, L.d_ctl, sizeof(QCtl), hipMemcpyDeviceToHost, L.stream));
-		HIPCHK(hipEventRecord(L.ev_ctl[0], L.stream));
 		t_submit_ += now_ms() - t0;
 	};
 	// fold a chunk's read-back into the parameters of the chunks still to be queued

@@ -1039,6 +1039,16 @@ def test_trimmed_tiny_proven_optimum_vs_oracle(pkg, oracle_mod):
     w = float(eng.get_best_error())
     print("trimmed tiny1, default mode: sse %.7g" % w)
     assert w <= o["sse"] * (1 + 1e-4) and o["sse"] - w <= eng.sse_threshold
+    cw, Rw, tw = eng.counters, eng.optR.copy(), eng.optT.copy()
+    eng.registration.close()
+    # ... and the same search cut into four lanes per batch (trimmed bounds: one workgroup per expansion, own lists per lane): the same optimum
+    eng = pkg.FastGoICP(tgt, src, 4e-3, trim_fraction=0.1, lanes=4, lane_min_searches=2)
+    eng.run()
+    cl = eng.counters
+    print("trimmed tiny1, four lanes: sse %.7g, cube bounds %d vs %d, two-or-more-lane batches %d" % (eng.get_best_error(), cl.cubes, cw.cubes, cl.lane_batches))
+    assert cl.lane_batches > 0 and abs(float(eng.get_best_error()) - w) <= 1e-6 * w
+    assert rot_angle(eng.optR, Rw) <= 1e-6 and np.linalg.norm(eng.optT - tw) <= 1e-6
+    assert cl.rot_pops == cw.rot_pops and abs(cl.cubes - cw.cubes) <= 0.01 * cw.cubes
     eng.registration.close()
 
 

@@ -295,8 +295,8 @@ private:
 	void free_lane(QLane& L);
 	void ensure_lane(int li, size_t nsearch);
 	double last_round_work_ = 0, lane_min_work_ = 64e6;    // point-expansions (expansions x source points) of the previous batch's mean round / the auto mode's bar
-	int auto_lanes_ = 3;                                    // lanes the auto mode cuts a batch into (env GOICP_AUTO_LANES; measured 2 / 3 / 4: bunny mse 3e-5 5.71 / 5.71 / 5.67 s,
-	                                                        // synthetic 40 k mse 3e-5 667 / 649 / 654 ms, 3 k points mse 3e-5 1 039 / 1 020 / 1 002 ms, bunny mse 1e-4 262 / 262 / 262 ms)
+	int auto_lanes_ = 3;                                    // lanes the auto mode cuts a batch into (env GOICP_AUTO_LANES; measured 2 / 3 / 4 at the end of round 4: bunny mse 3e-5
+	                                                        // 5.06 / 5.02 / 5.48 s, synthetic 40 k mse 3e-5 621 / 621 / 681 ms, 3 k points mse 3e-5 1 033 / 1 016 / 1 100 ms, bunny mse 1e-4 259 / 261 / 268 ms)
 	int lanes_ = 0, lane_min_searches_ = 64;                // Params::lanes / lane_min_searches (env GOICP_LANES / GOICP_LANE_MIN override, tuning only)
 	bool tiles_usable() const;
 	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration

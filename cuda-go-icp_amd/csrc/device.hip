@@ -1629,177 +1629,6 @@ __device__ __forceinline__ RowNn rows_nearest(const KdDesc& kd, const DtDesc& dt
 	return r;
 }
 
-// ---- EIGHT queries per wavefront (round 4): a query is walked by an 8-lane half row, each lane holding eight of a group's 64 child
-// boxes and two of a leaf's 16 slots.  The per-step selection logic (row minima, ballots, taking children in ascending order) costs a
-// wavefront the same as with four queries, the box tests and leaf scans double: ~1.45x the instructions per wavefront for 2x the queries
-// -- the pass is bound by instruction issue.  Same walk (children in ascending key order, four leaves per step, the nearest-point table's
-// candidate first), same exactness argument as rows_nearest; the child's sub-index takes three low key bits instead of two.
-struct Box6x8 { float4 lox[2], loy[2], loz[2], hix[2], hiy[2], hiz[2]; };   // the eight children 8l..8l+7 of a lane
-__device__ __forceinline__ Box6x8 load_child_boxes8(const float* __restrict__ g, int l)
-{
-	const float4* r = reinterpret_cast<const float4*>(g);
-	Box6x8 b;
-#pragma unroll
-	for (int h = 0; h < 2; h++) {
-		b.lox[h] = r[2 * l + h]; b.loy[h] = r[16 + 2 * l + h]; b.loz[h] = r[32 + 2 * l + h];
-		b.hix[h] = r[48 + 2 * l + h]; b.hiy[h] = r[64 + 2 * l + h]; b.hiz[h] = r[80 + 2 * l + h];
-	}
-	return b;
-}
-__device__ __forceinline__ void boxes_keys8(const Box6x8& b, float qx, float qy, float qz, unsigned key[8])
-{
-#pragma unroll
-	for (int h = 0; h < 2; h++) {
-		float lb[4];
-		boxes_lb4(Box6x4{b.lox[h], b.loy[h], b.loz[h], b.hix[h], b.hiy[h], b.hiz[h]}, qx, qy, qz, lb);
-#pragma unroll
-		for (int j = 0; j < 4; j++) key[4 * h + j] = (__float_as_uint(lb[j]) & ~7u) | (unsigned)(4 * h + j);
-	}
-}
-__device__ __forceinline__ unsigned row8_min_u32(unsigned v)     // min over the lane's 8-lane half row, in every lane
-{
-	v = min(v, dpp_u32<0xB1>(v));     // quad_perm [1,0,3,2]
-	v = min(v, dpp_u32<0x4E>(v));     // quad_perm [2,3,0,1]
-	v = min(v, dpp_u32<0x141>(v));    // row_half_mirror
-	return v;
-}
-__device__ __forceinline__ unsigned row8_take(unsigned key[8], int l, int hr, int& child)
-{
-	const unsigned mine = min(min(min(key[0], key[1]), min(key[2], key[3])), min(min(key[4], key[5]), min(key[6], key[7])));
-	const unsigned m = row8_min_u32(mine);
-	const unsigned owners = (unsigned)(__ballot(mine == m) >> (8 * hr)) & 0xffu;
-	const int wl = __ffs((int)owners) - 1;
-	const unsigned j = m & 7u;
-	if (l == wl) {
-#pragma unroll
-		for (int k = 0; k < 8; k++) key[k] = j == (unsigned)k ? 0xffffffffu : key[k];
-	}
-	child = 8 * wl + (int)j;
-	return m;
-}
-
-template <int K, int LAYOUT>
-__device__ __forceinline__ RowNn rows_nearest8(const KdDesc& kd, const DtDesc& dt, const Box6x8& rootb, int l, int hr,
-                                               float qx, float qy, float qz, bool active)
-{
-	unsigned key[K][8];
-	int node[K];
-	node[0] = 0;
-	boxes_keys8(rootb, qx, qy, qz, key[0]);
-#pragma unroll
-	for (int L = 1; L < K; L++) {
-		node[L] = 0;
-#pragma unroll
-		for (int j = 0; j < 8; j++) key[L][j] = 0xffffffffu;
-	}
-	Box6x8 fb = rootb;
-	if constexpr (K > 1) {
-		row8_take(key[0], l, hr, node[1]);
-		fb = load_child_boxes8(kd.boxes[1] + (size_t)node[1] * 384, l);
-	}
-	RowNn r{0.f, INT_MAX, false, 0.f, 0.f, 0.f, 0, INFINITY};
-	if (dt.nn_ids) {
-		// the same start as rows_nearest: a real candidate from the nearest-point table, held by lane 0 of the half row
-		const int V1 = dt.V - 1;
-		const int ix = min(max((int)rintf((qx - dt.xmin_f) * dt.scale_f), 0), V1);
-		const int iy = min(max((int)rintf((qy - dt.ymin_f) * dt.scale_f), 0), V1);
-		const int iz = min(max((int)rintf((qz - dt.zmin_f) * dt.scale_f), 0), V1);
-		size_t off;
-		if (LAYOUT == 0) off = ((size_t)iz * dt.V + iy) * dt.V + ix;
-		else off = (((size_t)(iz >> 2) * dt.VB + (iy >> 2)) * dt.VB + (ix >> 2)) * 64 + (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3));
-		const int slot = dt.nn_ids[off];
-		const float4 pt = kd.pts[slot];
-		const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
-		float e = d0 * d0;
-		e += d1 * d1;
-		e += d2 * d2;
-		r.best = e; r.idx = __float_as_int(pt.w); r.mine = l == 0; r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = slot;
-	} else
-		r.best = nn_upper_bound<LAYOUT>(dt, qx, qy, qz);
-	unsigned bbits = __float_as_uint(r.best);
-	int d = 0;
-	if constexpr (K > 1) {
-		boxes_keys8(fb, qx, qy, qz, key[1]);
-		d = 1;
-	}
-	bool done = !active;
-	while (__any(!done)) {
-		bool acted = done;
-#pragma unroll
-		for (int L = K - 1; L >= 0; L--) {
-			if (!acted && d == L) {
-				int c;
-				const unsigned m = row8_take(key[L], l, hr, c);
-				if ((m & ~7u) > bbits) {                             // nothing left within the best distance
-					if (L == 0) { done = true; acted = true; }
-					else d = L - 1;
-				} else if (L == K - 1) {
-					// ---- scan the four nearest remaining leaves of the group: a lane reads slots l and l + 8 of each (eight loads in flight) ----
-					const int f0 = node[L] * 64 + c;
-					int lf[4] = {f0, f0, f0, f0};
-					bool use[4] = {true, false, false, false};
-#pragma unroll
-					for (int j = 1; j < 4; j++) {
-						int cj;
-						const unsigned mj = row8_take(key[L], l, hr, cj);
-						use[j] = (mj & ~7u) <= bbits;
-						if (use[j]) lf[j] = node[L] * 64 + cj;
-					}
-					float4 pq[4][2];
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-						pq[j][0] = kd.pts[lf[j] * kLeafSlots + l];
-						pq[j][1] = kd.pts[lf[j] * kLeafSlots + l + 8];
-					}
-					float4 pt = pq[0][0];
-					int sb = lf[0] * kLeafSlots + l;
-					float e;
-					{
-						const float d0 = qx - pt.x, d1 = qy - pt.y, d2 = qz - pt.z;
-						e = d0 * d0;                                     // L2_Simple_Adaptor accumulation order
-						e += d1 * d1;
-						e += d2 * d2;
-					}
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-#pragma unroll
-						for (int h = 0; h < 2; h++) {
-							if (j == 0 && h == 0) continue;
-							const float d0 = qx - pq[j][h].x, d1 = qy - pq[j][h].y, d2 = qz - pq[j][h].z;
-							float dj = d0 * d0;
-							dj += d1 * d1;
-							dj += d2 * d2;
-							const bool wins = use[j] && (dj < e || (dj == e && __float_as_int(pq[j][h].w) < __float_as_int(pt.w)));
-							if (wins) { pt = pq[j][h]; e = dj; sb = lf[j] * kLeafSlots + l + 8 * h; }
-						}
-					}
-					const unsigned db = __float_as_uint(e);
-					const unsigned dmin = row8_min_u32(db);
-					const unsigned id = (unsigned)__float_as_int(pt.w);
-					const unsigned idmin = row8_min_u32(db == dmin ? id : 0x7fffffffu);   // ties -> lowest original index
-					if (dmin < bbits || (dmin == bbits && (int)idmin < r.idx)) {
-						bbits = dmin;
-						r.idx = (int)idmin;
-						r.mine = db == dmin && id == idmin;
-						r.mx = pt.x; r.my = pt.y; r.mz = pt.z; r.slot = sb;
-					}
-					acted = true;
-				} else {
-					// ---- enter the nearest remaining child group one level down ----
-					const int NL = L + 1 < K ? L + 1 : L;
-					node[NL] = node[L] * 64 + c;
-					const Box6x8 cb = load_child_boxes8(kd.boxes[NL] + (size_t)node[NL] * 384, l);
-					boxes_keys8(cb, qx, qy, qz, key[NL]);
-					d = NL;
-					acted = true;
-				}
-			}
-		}
-	}
-	r.best = __uint_as_float(bbits);
-	return r;
-}
-
 // Workgroup-shared state of one ICP iteration: the per-wavefront sums of the pass and the finalize's scratch, in ONE
 // __shared__ object (a second one beside it can make the compiler drain the memory pipeline before LDS reads).
 constexpr int kFinThreads = 1024;                  // the stand-alone finalize: 256 row streams x four float4 columns
@@ -1935,58 +1764,6 @@ __global__ __launch_bounds__(kIcpThreads, 2048 / kIcpThreads) void icp_pass_kern
 		if (!sh.last) return;
 		finalize_reduce<kIcpThreads>(partials, (int)gridDim.x, sh);
 		if (threadIdx.x < 64) finalize_rows(sh.sums, st, *st, (int)threadIdx.x);
-	}
-}
-
-// The pass with eight queries per wavefront (rows_nearest8), fixed-point sums.  A workgroup of four wavefronts walks the 32 queries of TWO
-// workgroups of icp_pass_kernel -- wavefront v takes over that kernel's wavefronts 2v and 2v + 1, half row by half row, for both dealings
-// (neighbours / strangers) -- and adds their terms up exactly as those two workgroups do (16 rows each, in row order, in float; then fixed
-// point): the accumulators receive the same integers, so an ICP run is bit-identical whichever kernel makes the passes.
-template <int K, int LAYOUT, bool STRIDED>
-__global__ __launch_bounds__(kIcpThreads) void icp_pass8_kernel(const float4* __restrict__ src, int N, IcpState* __restrict__ st, KdDesc kd, DtDesc dt,
-                                                               unsigned long long* __restrict__ acc)
-{
-	__shared__ float red[2 * (kIcpThreads / 16)][kIcpAcc];       // [two x 16 rows][16 sums]
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hr = lane >> 3, l = lane & 7;
-	const int v = blockIdx.x * (kIcpThreads / 64) + wave;         // this wavefront = icp_pass_kernel's wavefronts 2v, 2v + 1
-	const int nw = (N + 3) >> 2, wv = 2 * v + (hr >> 2), row = hr & 3;
-	const int i = STRIDED ? wv + row * nw : wv * 4 + row;
-	const bool valid = wv < nw && i < N;
-	const Box6x8 rootb = load_child_boxes8(kd.boxes[0], l);      // issued before the flag is tested: one round trip less
-	const float4 p = src[valid ? i : N - 1];
-	if (st->converged) return;                                   // loop already finished: queued launches drain
-	// jly_icp3d.hpp:222-224, left-to-right float sums
-	const float qx = st->R[0] * p.x + st->R[1] * p.y + st->R[2] * p.z + st->t[0];
-	const float qy = st->R[3] * p.x + st->R[4] * p.y + st->R[5] * p.z + st->t[1];
-	const float qz = st->R[6] * p.x + st->R[7] * p.y + st->R[8] * p.z + st->t[2];
-	const RowNn r = rows_nearest8<K, LAYOUT>(kd, dt, rootb, l, hr, qx, qy, qz, valid);
-	{
-		// the row of this query among the 2 x 16 rows of the workgroup: old workgroup (v >> 1) & 1, old row (wv & 3) * 4 + row
-		const int wrow = ((v >> 1) & 1) * 16 + (wv & 3) * 4 + row;
-		const bool owner = valid ? r.mine : l == 0;
-		if (owner) {
-			float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-			if (valid) {
-				const float ax = qx - st->cq[0], ay = qy - st->cq[1], az = qz - st->cq[2];   // pivots keep the covariance sums well conditioned
-				const float bx = r.mx - st->cm[0], by = r.my - st->cm[1], bz = r.mz - st->cm[2];
-				a0 = make_float4(ax, ay, az, bx);
-				a1 = make_float4(by, bz, ax * bx, ax * by);
-				a2 = make_float4(ax * bz, ay * bx, ay * by, ay * bz);
-				a3 = make_float4(az * bx, az * by, az * bz, r.best);
-			}
-			float4* dst = reinterpret_cast<float4*>(red[wrow]);
-			dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x < 2 * kIcpAcc) {
-		const int half = threadIdx.x >> 4, k = threadIdx.x & 15;
-		float sum = red[half * 16][k];
-#pragma unroll
-		for (int x = 1; x < 16; x++) sum += red[half * 16 + x][k];
-		const long long fx = __double2ll_rn((double)sum * (double)st->acc_scale);
-		unsigned long long* a = acc + (size_t)((2 * blockIdx.x + half) & (kIcpAccReplicas - 1)) * kIcpAcc + k;
-		__hip_atomic_fetch_add(a, (unsigned long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -2604,14 +2381,6 @@ static void launch_pass_acc(const float4* src, int N, IcpState* st, const KdDesc
 	}
 }
 
-template <int K>
-static void launch_pass8(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, unsigned long long* acc, hipStream_t stream)
-{
-	const dim3 grid((icp_blocks(N) + 1) / 2), block(kIcpThreads);
-	if (N <= kIcpStridedMaxN) hipLaunchKernelGGL((icp_pass8_kernel<K, 1, true>), grid, block, 0, stream, src, N, st, kd, dt, acc);
-	else hipLaunchKernelGGL((icp_pass8_kernel<K, 1, false>), grid, block, 0, stream, src, N, st, kd, dt, acc);
-}
-
 template <int K, bool FUSED>
 static void launch_pass_k(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials, int* ticket, float4* nn_cache,
                           int* hits, hipStream_t stream)
@@ -2653,15 +2422,8 @@ hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState
 
 // ticket != nullptr: one fused launch per iteration; nullptr: pass + stand-alone finalize (same arithmetic, bit-identical)
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* st, const KdDesc& kd, const DtDesc& dt, float* partials,
-                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc, bool rows8)
+                                int* ticket, float4* nn_cache, int* hits, hipStream_t stream, unsigned long long* acc)
 {
-	if (!ticket && acc && dt.layout && rows8 && !nn_cache) {
-		if (kd.K == 1) launch_pass8<1>(src, N, st, kd, dt, acc, stream);
-		else if (kd.K == 2) launch_pass8<2>(src, N, st, kd, dt, acc, stream);
-		else launch_pass8<3>(src, N, st, kd, dt, acc, stream);
-		hipLaunchKernelGGL(icp_finalize_update_acc, dim3(1), dim3(kFinAccThreads), 0, stream, acc, st);
-		return hipGetLastError();
-	}
 	if (!ticket && acc && dt.layout) {
 		// the default form: fixed-point sums, no rows of partial sums
 		if (kd.K == 1) launch_pass_acc<1>(src, N, st, kd, dt, acc, nn_cache, hits, stream);

@@ -232,8 +232,7 @@ size_t icp_partials_floats(int N);   // floats the `partials` buffer of launch_i
 // acc: kIcpAccReplicas x 16 zeroed 64-bit words (kept zero between iterations by the finalize) -> clouds of up to kIcpStridedMaxN
 // points sum there instead of writing a row of partial sums per workgroup; nullptr -> rows for every size
 hipError_t launch_icp_iteration(const float4* src, int N, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,
-                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr,
-                                bool rows8 = false);      // rows8 (with acc, a bricked DT, no ticket, no cache): eight queries per wavefront -- the same integers reach the accumulators
+                                float* partials, int* ticket, float4* nn_cache, int* hit_counter, hipStream_t stream, unsigned long long* acc = nullptr);
 // trimmed iteration: only the `num` nearest correspondences enter the sums (IcpState.n must be num)
 int icp_trim_blocks(int N);
 hipError_t launch_icp_iteration_trim(const float4* src, int N, int num, IcpState* d_state, const KdDesc& kd, const DtDesc& dt,

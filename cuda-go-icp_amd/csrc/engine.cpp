@@ -163,8 +163,6 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	{ const char* e = std::getenv("GOICP_LANES"); if (e) lanes_ = std::atoi(e); }                                  // tuning only (tools/lanes_probe.py)
 	{ const char* e = std::getenv("GOICP_LANE_MIN"); if (e) lane_min_searches_ = std::max(2, std::atoi(e)); }
 	{ const char* e = std::getenv("GOICP_LANE_MIN_WORK"); if (e) lane_min_work_ = std::atof(e); }
-	icp_rows8_ = p_.icp_rows8 != 0;
-	{ const char* e = std::getenv("GOICP_ICP_ROWS8"); if (e) icp_rows8_ = std::atoi(e) != 0; }        // tuning only (tools/icp_rows8_probe.py)
 	{ const char* e = std::getenv("GOICP_TILE_STICKY_SHARE"); if (e) tile_sticky_share_ = std::atof(e); }
 	{ const char* e = std::getenv("GOICP_AUTO_LANES"); if (e) auto_lanes_ = std::min(kMaxLanes, std::max(2, std::atoi(e))); }
 
@@ -847,8 +845,7 @@ void Engine::icp_launch_one()
 		HIPCHK(launch_icp_iteration_trim(d_src_, (int)N_, inliers_, d_icp_state_, kd_, dt_, d_nn_d2_, d_nn_slot_, d_include_, d_icp_partials_, stream_));
 	else
 		HIPCHK(launch_icp_iteration(d_src_, (int)N_, d_icp_state_, kd_, dt_, d_icp_partials_, p_.icp_fused ? d_icp_ticket_ : nullptr,
-		                            (p_.icp_nn_cache == 1 || icp_cache_active_) ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_,
-		                            icp_rows8_));
+		                            (p_.icp_nn_cache == 1 || icp_cache_active_) ? d_nn_cache_ : nullptr, count_hits_ ? d_icp_ticket_ + 8 : nullptr, stream_, d_icp_acc_));
 }
 
 void Engine::icp_state_fetch()

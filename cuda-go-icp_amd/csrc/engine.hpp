@@ -59,7 +59,6 @@ struct Params {
 	                              // lane_min_searches inner searches is cut into lanes by rotation slot and the lanes run their lock-step rounds side by side on their own
 	                              // streams (own lists, own control block): one lane's dependent launches drain beside the others' (run_inner_device)
 	int lane_min_searches = 64;
-	int icp_rows8 = 1;            // 1 (default): the ICP pass walks eight queries per wavefront (8-lane half rows; bit-identical sums); 0: four (16-lane rows)
 	int stream_priority = 0;      // 1: the engine's stream gets the highest priority of the device (an ICP engine beside a bounds engine on one GPU: tools/overlap_probe.py)
 	int icp_fused = 0;            // 1: one launch per ICP iteration (last workgroup finalizes); 0: pass + finalize launches (A/B, bit-identical)
 	float trim_fraction = 0.f;    // GoICP::trimFraction (jly_goicp.h:116; the reference hard-wires 0, jly_goicp.cpp:55)
@@ -302,7 +301,6 @@ private:
 	bool tiles_usable() const;
 	long long sel_hist_[4][4] = {};       // verbose: QCtl::sel_hist summed over the registration
 	double tile_sticky_share_ = 0.5;      // ... when at least this share of the previous batch's cube bounds came from tiles (env GOICP_TILE_STICKY_SHARE, tuning only)
-	bool icp_rows8_ = true;
 	bool tile_sticky_ = false;            // lds_tiles == 2: the previous batch evaluated expansions from tiles -> this batch launches the tile list in every round
 	long long tile_rounds_ = 0;           // rounds whose tile evaluation was launched
 	long long queue_rounds_ = 0, queue_fallbacks_ = 0;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Eight queries per wavefront in the ICP pass (8-lane half rows; env GOICP_ICP_ROWS8 = 1, the default) against four (16-lane rows; = 0), one
+"""(Runs at commit d43fdcd only: the variant was measured slower and removed -- EXPERIMENTS.md R4.17.)
+Eight queries per wavefront in the ICP pass (8-lane half rows; env GOICP_ICP_ROWS8 = 1, the default) against four (16-lane rows; = 0), one
 process per setting: ICP iterations/s over a forced 200-iteration trajectory from the identity pose, one iteration frozen at the converged pose,
 the registration -- and the bits of the poses, which must not differ (the accumulators receive the same integers)."""
 import os

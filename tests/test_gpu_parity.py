@@ -1207,6 +1207,26 @@ def test_poll_and_cancel_while_running(pkg, bunny_model, bunny_data):
     th.join(timeout=30)
     assert not th.is_alive() and eng.finished
     assert eng.get_best_error() <= seen[-1]
+    # the default (device-queue) search with every batch cut into lanes: cancelled in the middle of multi-stream rounds it returns promptly,
+    # and the engine registers again afterwards (streams drained, per-lane state reusable) with a result that is still an upper bound
+    eng2 = pkg.FastGoICP(bunny_model, bunny_data, 1e-9, lanes=3, lane_min_searches=2)
+    th = threading.Thread(target=eng2.run)
+    th.start()
+    time.sleep(0.5)
+    assert th.is_alive()
+    t1 = time.time()
+    eng2.cancel()
+    th.join(timeout=30)
+    assert not th.is_alive() and eng2.finished and time.time() - t1 < 5.0
+    first = float(eng2.get_best_error())
+    assert eng2.counters.lane_batches > 0 and np.isfinite(first)
+    th = threading.Thread(target=eng2.run)
+    th.start()
+    time.sleep(0.3)
+    eng2.cancel()
+    th.join(timeout=30)
+    assert not th.is_alive() and np.isfinite(float(eng2.get_best_error()))
+    eng2.registration.close()
 
 
 # ----------------------------------------------------------------------------------------------

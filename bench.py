@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--s2-steps", type=int, default=3, help="launches of the S2 (1 M points, DT 512^3) leg in the default run (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-deep", action="store_true", help="skip the prove-the-optimum registration of the N = 1 line (~5 s)")
     ap.add_argument("--dt-layout", type=int, default=1)
     ap.add_argument("--dt-size", type=int, default=300, help="tuning only: the BASELINE workload is 300")
     ap.add_argument("--kd-gpu-build", type=int, default=-1, help="tuning only: target hierarchy built on the device 1 / host 0 / auto -1")
@@ -630,6 +631,23 @@ def main():
                             "rot_error_rad": round(float(2 * np.arcsin(min(1.0, dR / (2 * np.sqrt(2))))), 6),
                             "trans_error": round(float(np.linalg.norm(np.asarray(r.optT, np.float64) - np.array(gj["t"]))), 6),
                             "pose_error_vs": "the reference CPU Go-ICP's optimum (tests/golden/e2e_bunny_full.json); tolerance 2e-3 rad / 2e-3 (SURVEY 8c)"})
+        # ---- the prove-the-optimum registration (bunny at --deep-mse, below the optimum's error: no early exit; the search expands every node whose
+        # lower bound stays SSEThresh under the optimum -- 343 M cube bounds): what a registration costs when it has to certify global optimality.
+        # At N > 1 the same run is the world-1 side of e2e_sharded.deep, so it is made here only at N = 1
+        e2e_deep = None
+        if not args.no_e2e and world == 1 and args.workload == "bunny" and args.deep_mse > 0 and not args.no_deep:
+            engd = pkg.FastGoICP(model, data, args.deep_mse, dt_size=V, dt_layout=args.dt_layout, device=local_rank)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            engd.run()
+            walld = time.perf_counter() - t1
+            cd = engd.counters
+            e2e_deep = {"workload": "bunny (N=%d, M=%d, DT %d^3) at mse %g: SSEThresh below the optimum's error, the search proves the optimum" % (N, M, V, args.deep_mse),
+                        "register_s": round(walld, 4), "sse": float(engd.get_best_error()), "sse_threshold": float(engd.sse_threshold), "cube_bounds": int(cd.cubes),
+                        "cube_bounds_per_s": round(cd.cubes / walld, 1), "from_lds_tiles_pct": round(800.0 * cd.tile_expansions / max(cd.cubes, 1), 1),
+                        "rot_pops": int(cd.rot_pops), "icp_iters": int(cd.icp_iters), "batches_in_lanes": int(cd.lane_batches), "queue_fallbacks": int(cd.queue_fallbacks),
+                        "vs_microbench_rate": round(cd.cubes / walld / value, 3)}
+            engd.registration.close()
         cpu = None
         if not args.no_cpu:                      # rank 0's host cores, at every N (the other ranks wait at the next collective)
             c = cpu_baseline(reg, model, data)
@@ -657,7 +675,7 @@ def main():
                "value_repeats": {"n": len(repeats), "min": round(min(repeats), 1), "max": round(max(repeats), 1),
                                  "spread_pct": round(100 * (max(repeats) - min(repeats)) / value, 2)},
                "sustained": sustained,
-               "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_sharded": None}
+               "roofline": roofline, "generic_path": generic, "cpu_baseline": cpu, "icp": icp, "e2e": e2e, "e2e_deep": e2e_deep, "e2e_sharded": None}
     reg.close()
     del d_rots, d_cubes, d_ub, d_lb
 

@@ -205,8 +205,14 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 			count = sh.bcast;
 		}
 		if (count + (int)total > qp.cap) {
-			// still does not fit: flag it; the host re-runs the whole batch through its own queues (nothing is lost)
-			if (tid == 0) { atomicExch(&ctl->overflow, 1); S->done = 1; S->n_parents = 0; }
+			// still does not fit: this search stops here and the host re-runs it through its own queues, from its original incumbent (nothing is
+			// lost) -- alone (soft_overflow: the other searches of the batch are not its hostages; re-running a whole 1 024-search batch on the
+			// host cost the prove-the-optimum bunny 0.8 of its 5.0 s), or with the whole batch
+			if (tid == 0) {
+				if (qp.soft_overflow) S->done = 2;
+				else { atomicExch(&ctl->overflow, 1); S->done = 1; }
+				S->n_parents = 0;
+			}
 			return;
 		}
 		if (push) {

@@ -112,7 +112,7 @@ struct QSearch {                    // one GoICP::InnerBnB call (jly_goicp.cpp:2
 	float coeff;                    // rotation uncertainty coefficient of this pass, 0 for the upper-bound pass
 	int32_t rot;                    // rotation slot
 	int32_t count;                  // queued nodes
-	int32_t done, improved;
+	int32_t done, improved;         // done: 1 = finished, 2 = stopped because its queue outgrew the slab (QParams::soft_overflow)
 	int32_t n_parents, parent_off;  // this round's expansions in the round's list
 	int32_t pops, cubes;            // tNodeCount of this search / children evaluated
 	float bx, by, bz, bw;           // best child (corner, width), valid when improved
@@ -155,6 +155,8 @@ struct QParams {
 	float root_x, root_y, root_z, root_w;
 	int32_t boxed, depth;           // translation range culling / depth limit (0 = none)
 	int32_t cap;                    // nodes a queue may hold (<= kQueueCap; smaller values only to exercise the overflow path)
+	int32_t soft_overflow;          // 1: a search whose queue outgrows its slab stops with QSearch::done = 2 and the others go on (the host re-runs that search
+	                                // alone through its own queues); 0: it raises QCtl::overflow and the whole batch goes back
 	float lo[3], hi[3];
 	int32_t tile_on;                // 1: searches that qualify are listed in the tile list this round (its evaluation is launched)
 	int32_t tile_min;               // fewest expansions for the tile list (a lane group of the tile kernel = one expansion)

@@ -163,6 +163,7 @@ void Engine::init(const float* target, size_t M, const float* source, size_t N)
 	{ const char* e = std::getenv("GOICP_LANES"); if (e) lanes_ = std::atoi(e); }                                  // tuning only (tools/lanes_probe.py)
 	{ const char* e = std::getenv("GOICP_LANE_MIN"); if (e) lane_min_searches_ = std::max(2, std::atoi(e)); }
 	{ const char* e = std::getenv("GOICP_LANE_MIN_WORK"); if (e) lane_min_work_ = std::atof(e); }
+	{ const char* e = std::getenv("GOICP_SOFT_OVERFLOW"); if (e) soft_overflow_ = std::atoi(e) != 0; }      // A/B only
 	{ const char* e = std::getenv("GOICP_TILE_STICKY_SHARE"); if (e) tile_sticky_share_ = std::atof(e); }
 	{ const char* e = std::getenv("GOICP_AUTO_LANES"); if (e) auto_lanes_ = std::min(kMaxLanes, std::max(2, std::atoi(e))); }
 
@@ -1295,6 +1296,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		HIPCHK(hipMemcpyAsync(L.d_search, L.h_search, sizeof(QSearch) * Sl, hipMemcpyHostToDevice, L.stream));
 		r.qp = queue_params();
 		r.qp.list_cap = L.list_cap; r.qp.seg_cap = L.seg_cap;
+		r.qp.soft_overflow = soft_overflow_ ? 1 : 0;
 		r.qp.K = K;
 		r.qp.kmax = std::min(kQueueMaxPop, L.list_cap / (int)std::max<size_t>(Sl, 1));   // >= kQueueRoundPop: Sl <= the slots the lists were sized for
 		HIPCHK(launch_bnb_init(L.d_search, L.d_nodes, (int)Sl, r.qp, L.d_ctl, L.stream));
@@ -1437,6 +1439,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		for (size_t i = 0; i < run[li].idx.size(); i++) {
 			const QSearch& q = L.h_search[i];
 			InnerSearch& s = *searches[(size_t)run[li].idx[i]];
+			if (q.done == 2) { redo_.push_back(&s); continue; }          // its queue outgrew the slab: untouched here, re-run by run_inner through the host queues
 			s.best = q.best; s.improved = q.improved != 0; s.done = true;
 			s.best_node = Node{q.bx, q.by, q.bz, q.bw, 0.f, 0.f, 0};
 			s.pops = q.pops; s.cubes = q.cubes; s.min_ub = q.min_ub;
@@ -1453,10 +1456,19 @@ void Engine::run_inner(std::vector<InnerSearch*>& searches, const std::vector<Ro
 		if (s->rot_slot < 0 || (size_t)s->rot_slot >= rots.size()) throw std::logic_error("goicp: rotation slot out of range");
 	if (p_.device_queues && p_.trans_batch > 1) {
 		const double t_begin = now_ms();
+		redo_.clear();
 		const bool ok = run_inner_device(searches, rots);
 		bnb_ms_ += now_ms() - t_begin;
-		if (ok) return;
-		// a queue outgrew its slab: the batch is re-run through the host queues (the searches have not been touched)
+		if (ok && redo_.empty()) return;
+		if (ok) {
+			// searches whose queue outgrew its slab (they have not been touched): through the host queues, alone
+			queue_fallbacks_++; cnt_.queue_fallbacks++;
+			std::vector<InnerSearch*> redo;
+			redo.swap(redo_);
+			run_inner_host(redo, rots, true);
+			return;
+		}
+		// a round's lists overflowed: the whole batch is re-run through the host queues (the searches have not been touched)
 		run_inner_host(searches, rots, true);
 		return;
 	}

@@ -185,7 +185,9 @@ private:
 	void ensure_stage(int k, size_t B);
 	void run_inner(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);
 	void run_inner_host(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots, bool fallback = false);
-	bool run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);   // false: a queue overflowed, nothing was changed
+	bool run_inner_device(std::vector<InnerSearch*>& searches, const std::vector<Rot9>& rots);   // false: a round's lists overflowed, nothing was changed; redo_: searches whose own queue did
+	std::vector<InnerSearch*> redo_;
+	bool soft_overflow_ = true;       // env GOICP_SOFT_OVERFLOW = 0 (A/B only): a slab overflow sends the whole batch back, as before round 4
 	void ensure_queues(size_t nsearch);
 	void process_parents(const std::vector<Node>& parents);
 	struct Kid { Node node; float R[9]; float parent_lb; };                       // a rotation child and its Rodrigues matrix

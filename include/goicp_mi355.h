@@ -263,7 +263,8 @@ int goicp_eval_sse(goicp_handle h, const float R[9], const float t[3], float* ss
  * (src/goicp/jly_goicp.cpp:227-340).  best_node = {corner x,y,z, width}, written only on improvement. */
 typedef struct goicp_counters {
 	int64_t rot_pops, trans_pops, cubes, inner_calls, icp_runs, icp_iters, bounds_launches;
-	int64_t queue_fallbacks;     /* batches of inner searches re-run through the host queues because a device queue outgrew its slab */
+	int64_t queue_fallbacks;     /* batches of inner searches in which a device queue outgrew its slab: the searches concerned (only they, since round 4)
+	                              * were re-run through the host queues */
 	int64_t tile_expansions;     /* BnB expansions (8 cube bounds each, counted in `cubes` too) evaluated from LDS-staged DT tiles */
 	int64_t lane_batches;        /* batches of inner searches that ran as two lanes (goicp_params::lanes) */
 } goicp_counters;

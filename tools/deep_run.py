@@ -22,5 +22,5 @@ eng = pkg.FastGoICP(model, data, mse, **kw)
 for _ in range(int(os.environ.get("DEEP_RUN_REPEATS", "1"))):
     t0 = time.perf_counter(); eng.run(); wall = time.perf_counter() - t0
 c = eng.counters
-print("mse %g %s: %.3f s  sse %.6f  cube bounds %d  from tiles %.1f %%  rot nodes %d  rounds %d  lane batches %d" % (
-    mse, kw, wall, eng.get_best_error(), c.cubes, 800.0 * c.tile_expansions / c.cubes, c.rot_pops, c.bounds_launches, c.lane_batches), flush=True)
+print("mse %g %s: %.3f s  sse %.6f  cube bounds %d  from tiles %.1f %%  rot nodes %d  rounds %d  lane batches %d  queue fallbacks %d" % (
+    mse, kw, wall, eng.get_best_error(), c.cubes, 800.0 * c.tile_expansions / c.cubes, c.rot_pops, c.bounds_launches, c.lane_batches, c.queue_fallbacks), flush=True)

@@ -1543,6 +1543,20 @@ def test_device_queues_match_host_queues(pkg, bunny_model, bunny_data10):
     assert c.get_best_error() <= 1.02 * ge["sse"] and c.get_best_error() < ge["sse_threshold"]
     for r in (dev, host, tiny, a.registration, b.registration, c.registration):
         r.close()
+    # ... and on a CONVERGED search (the reference's own GoICP::Register proves this optimum: tests/golden/e2e_small6.json): with room for 512 nodes per
+    # queue the long searches stop alone (QSearch::done = 2) and are re-run through the host queues while the rest of each batch stays on the device
+    # -- the search as a whole still proves the same optimum with (nearly) the same node counts
+    from conftest import small_problem
+    tgt, src, _, _ = small_problem(6)
+    g6 = golden("e2e_small6")
+    e = pkg.FastGoICP(tgt, src, g6["mse_threshold"], queue_cap=512)
+    e.run()
+    ce = e.counters
+    print("queue_cap 512 on small6: %d batches with searches re-run on the host, sse %.7g (reference %.7g), rotation nodes %d (reference %d)" % (
+        ce.queue_fallbacks, e.get_best_error(), g6["sse"], ce.rot_pops, g6["rNodeCount"]))
+    assert ce.queue_fallbacks >= 1 and abs(float(e.get_best_error()) - g6["sse"]) <= 1e-5 * g6["sse"]
+    assert rot_angle(e.optR, np.array(g6["R"])) <= 1e-5 and abs(ce.rot_pops - g6["rNodeCount"]) <= 0.01 * g6["rNodeCount"]
+    e.registration.close()
 
 
 def test_queue_purges_dead_nodes_before_overflow(pkg):

@@ -517,7 +517,12 @@ __device__ __forceinline__ void queue_round(QShared& sh, QSearch* __restrict__ S
 }
 
 // nodes of search s: q[s * kQueueCap ...]
-__global__ __launch_bounds__(kQThreads, 8) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
+// WAVES = wavefronts per SIMD the kernel is built for.  8: 64 VGPRs, two searches per CU -- the deep batches, where queue kernels of several
+// lanes and long bound evaluations compete for the chip (99 spilled registers, nearly all on the purge path).  4: 128 VGPRs, no spill, one search
+// per CU -- every other batch: a default registration's queue kernels are latency chains (bunny 32.5 -> 31.9 ms, skull 6.3 -> 6.2, bunny mse 1e-4
+// 260 -> 253 ms; on the prove-the-optimum run the same build costs 5.02 -> 5.18 s, hence the two forms).  Same code, same results.
+template <int WAVES>
+__global__ __launch_bounds__(kQThreads, WAVES) void bnb_queue_kernel(QSearch* __restrict__ searches, QNode* __restrict__ q, QParams qp,
                                                               const ParentRec* __restrict__ prev_parents, ParentRec* __restrict__ parents,
                                                               const float* __restrict__ ubs, const float* __restrict__ lbs,
                                                               const float* __restrict__ scratch, QCtl* __restrict__ ctl, int parity, QTile tile, int* __restrict__ parent_search)
@@ -579,7 +584,8 @@ hipError_t launch_bnb_init(QSearch* searches, QNode* q, int nsearch, const QPara
 }
 
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
-                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile, int* parent_search)
+                            const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile, int* parent_search,
+                            bool deep)
 {
 	if (nsearch <= 0) return hipSuccess;
 	if (qp.K < 1 || qp.K > kQueueMaxPop) return hipErrorInvalidValue;
@@ -587,7 +593,8 @@ hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QPar
 	QParams q2 = qp;
 	if (tile && tile->ub) t = *tile;
 	else { q2.tile_on = 0; }                                               // no buffers: nothing may be listed there
-	hipLaunchKernelGGL(bnb_queue_kernel, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t, parent_search);
+	if (deep) hipLaunchKernelGGL(bnb_queue_kernel<8>, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t, parent_search);
+	else hipLaunchKernelGGL(bnb_queue_kernel<4>, dim3(nsearch), dim3(kQThreads), 0, stream, searches, q, q2, prev_parents, parents, ubs, lbs, scratch, ctl, parity, t, parent_search);
 	return hipGetLastError();
 }
 

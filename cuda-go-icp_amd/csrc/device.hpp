@@ -182,7 +182,8 @@ hipError_t launch_bnb_init_list(QSearch* searches, QNode* q, const QInit* d_list
 // digest the previous round (prev_parents + ubs/lbs), select this round's expansions into `parents`, count them in ctl->n_groups[parity]
 hipError_t launch_bnb_queue(QSearch* searches, QNode* q, int nsearch, const QParams& qp, const ParentRec* prev_parents, ParentRec* parents,
                             const float* ubs, const float* lbs, const float* scratch, QCtl* ctl, int parity, hipStream_t stream, const QTile* tile = nullptr,
-                            int* parent_search = nullptr);       // parent_search[g] = the search that listed expansion g of the direct list (for the twin test)
+                            int* parent_search = nullptr,        // parent_search[g] = the search that listed expansion g of the direct list (for the twin test)
+                            bool deep = true);                   // deep: the 64-VGPR build (two searches per CU; batches of a prove-the-optimum run), else the 128-VGPR one (no spills)
 // bounds of the tile list of round `parity` (segment count known to the device only); fixed grid
 hipError_t launch_bounds_tile_queue(const float4* src, int N, const DtDesc& dt, const Rot9* rots, const QTile& tile, QCtl* ctl, int parity, hipStream_t stream);
 size_t bounds_tile_queue_scratch_floats(int max_groups);

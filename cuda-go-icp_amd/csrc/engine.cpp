@@ -1311,6 +1311,10 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		r.qp.tile_on = r.tiles && (p_.lds_tiles == 1 || (p_.lds_tiles == 2 && tile_sticky_)) ? 1 : 0;
 		L.tile_hint_seen = 0;
 	}
+	// which build of the queue kernel: the batches of a deep run (following one that was fed from tiles: long bound evaluations, queue kernels of several
+	// lanes side by side) take the 64-VGPR one (two searches per CU), the others the 128-VGPR one (no spills).  Measured (all-64 -> by batch): skull 6.3 ->
+	// 6.17 ms, synthetic 40 k 11.3 -> 11.05 ms, bunny mse 1e-4 260 -> 255 ms, synthetic 40 k mse 3e-5 617 -> 609 ms; all-128: bunny mse 3e-5 5.02 -> 5.18 s
+	const bool deep_batch = tile_sticky_;
 	// One chunk of rounds of a lane: queue kernel + (sort) + bound evaluation(s) per round; the control block is read back behind the LAST round's queue kernel.
 	auto submit = [&](Run& r) {
 		const double t0 = now_ms();
@@ -1321,7 +1325,7 @@ bool Engine::run_inner_device(std::vector<InnerSearch*>& searches, const std::ve
 		for (int k = 0; k < r.chunk; k++) {
 			const int parity = r.parity;
 			HIPCHK(launch_bnb_queue(L.d_search, L.d_nodes, (int)Sl, qp, L.d_parents[parity ^ 1], L.d_parents[parity], L.d_ub, L.d_lb, L.d_scratch, L.d_ctl, parity, L.stream, r.tiles ? &L.tile : nullptr,
-			                        r.twins ? L.d_psearch[parity] : nullptr));
+			                        r.twins ? L.d_psearch[parity] : nullptr, deep_batch));
 			if (k == r.chunk - 1) {
 				// Everything the host looks at after a chunk -- what the last round listed, how many searches are running, overflow, the tile
 				// hint -- is written by THIS kernel; the bound evaluations behind it only fill in the bounds the next queue kernel digests.  So the

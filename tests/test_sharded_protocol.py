@@ -261,3 +261,31 @@ def test_bench_plain_launch_two_ranks_gloo():
     s2 = sh["s2"]
     assert s2["sse"] < s2["sse_threshold"] and s2["rot_error_rad_vs_ground_truth"] <= 3e-2 and s2["trans_error_vs_ground_truth"] <= 1e-2
     assert s2["world1"]["rot_pops"] >= 50 and s2["rot_pops_all_ranks"] >= 50
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_contract():
+    """`python3 bench.py` at N = 1 (the driver's BENCH run, shortened): ONE JSON line with the contract's keys, a roofline object for the dominant kernel
+    whose `achieved` is the line's own launch time turned into look-ups/s, the default registration (`e2e`) inside the tolerance against the reference's
+    optimum, and the prove-the-optimum registration (`e2e_deep`, here at mse 1e-4) consistent with its own counters."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--prewarm", "2", "--sustain-s", "0", "--s2-steps", "0",
+                        "--no-cpu", "--e2e-repeats", "1", "--deep-mse", "1e-4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["metric"] == "bnb_cube_bounds_per_s" and j["unit"] == "cube-bounds/s"
+    assert abs(j["value"] - j["config"]["cubes_per_step_per_gpu"] * 3 / (j["ms_per_step"] * 3e-3)) <= 0.01 * j["value"]
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-3 and abs(rf["achieved"] - rf["lookups_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) <= 0.01 * rf["achieved"]
+    if rf["traffic"] is not None:
+        assert rf["traffic_profile_kernel_hash"] == rf["library_kernel_hash"]          # counter traffic is quoted only from a profile of THESE kernels
+    e = j["e2e"]
+    assert e["sse"] < 4.5723 * 1.001 and e["rot_error_rad"] <= 2e-3 and e["trans_error"] <= 2e-3
+    d = j["e2e_deep"]
+    assert d["sse"] > d["sse_threshold"] and d["rot_pops"] > 900 and abs(d["cube_bounds_per_s"] - d["cube_bounds"] / d["register_s"]) <= 0.01 * d["cube_bounds_per_s"]
+    assert d["sse"] <= e["sse"] + 1e-6                                               # the deeper search cannot end worse
